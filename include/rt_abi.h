@@ -1,0 +1,166 @@
+/* rt_abi.h -- C ABI of the MI355X trace loop.
+ *
+ * The library behind this header (raytracer_amd/csrc -> libraytracer_amd.so)
+ * replaces exactly one call of the reference program: `scene->render()` in
+ * main (raytracer.cpp:857), i.e. Scene::render / traceRay / traceShadowRay /
+ * phongShade (raytracer.cpp:497-581) together with the primitive methods they
+ * reach (raytracer.cpp:251-272, 307-373, 389-419), Camera::generateRay
+ * (raytracer.cpp:441-447), the Light methods (raytracer.cpp:108-128) and the
+ * pixel quantisation of Film::writeToFilm (raytracer.cpp:174-203).  Parsing
+ * stays on the host and so does PNG encoding.
+ *
+ * Everything crossing the boundary is plain C: pointers, sizes, ints.  All
+ * calls return 0 on success or a negative rt_status; rt_last_error() gives
+ * the message of the calling thread's last failure.  The library never
+ * exits or aborts the process and has no CPU fallback: with no usable GPU
+ * rt_upload_scene fails with RT_ERR_DEVICE.
+ */
+#ifndef RT_ABI_H
+#define RT_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_ARG = -1,     /* bad argument / malformed scene description */
+    RT_ERR_DEVICE = -2,  /* a HIP call failed (no GPU, out of memory, launch failure) */
+    RT_ERR_RANGE = -3,   /* tile or buffer outside the frame */
+    RT_ERR_STATE = -4    /* call not valid in the current state */
+} rt_status;
+
+/* Material (raytracer.cpp:44-64); sp holds the reference's float exactly. */
+typedef struct rt_material {
+    double ka[3], kd[3], ks[3], kr[3];
+    double sp;
+} rt_material;
+
+/* Polygon::transform / inverseTransform / inverseTranspose (raytracer.cpp:241-250),
+ * row-major.  The caller computes inv and inv_t with the reference's own
+ * mat4::inverse()/transpose() (algebra3.h:1130, 1123) so the bits agree. */
+typedef struct rt_transform {
+    double m[16], inv[16], inv_t[16];
+} rt_transform;
+
+/* Light (raytracer.cpp:86-106).  For a directional light `pos` is the
+ * direction the light travels in (lightVec = -pos, raytracer.cpp:112). */
+typedef struct rt_light {
+    double color[3], pos[3];
+    int32_t falloff;   /* 0, 1 or 2: intensity = color / dist^falloff (raytracer.cpp:121-128) */
+    int32_t is_point;
+} rt_light;
+
+/* Flat description of a parsed Scene (raytracer.cpp:457-466).  Objects keep
+ * the order of Scene::objects: nearest-hit ties go to the lowest index
+ * (raytracer.cpp:525) and the shading ray is the LAST object's transformed
+ * ray (raytracer.cpp:518-520, 536, 571), so the order is part of the input.
+ * All pointers are host pointers owned by the caller; rt_upload_scene copies.
+ */
+typedef struct rt_scene_desc {
+    uint32_t struct_size;      /* = sizeof(rt_scene_desc) */
+    int32_t width, height;     /* Scene::width/height (raytracer.cpp:465) */
+    int32_t max_depth;         /* Scene::maxDepth: up to max_depth+1 levels (raytracer.cpp:477, 539) */
+    float eps;                 /* Scene::eps, 0.05f in main (raytracer.cpp:849) */
+    float shadow_eps;          /* 0.1f in intersects() (raytracer.cpp:308, 390) */
+    double cam_eye[3], cam_ll[3], cam_lr[3], cam_ul[3], cam_ur[3]; /* Camera (raytracer.cpp:425) */
+    double ambient[3];         /* Scene::ambientLight.color (raytracer.cpp:463) */
+    int32_t n_objects, n_materials, n_transforms, n_lights;
+    const int32_t* obj_kind;      /* [n_objects] 0 = Triangle, 1 = Sphere */
+    const int32_t* obj_material;  /* [n_objects] index into materials */
+    const int32_t* obj_transform; /* [n_objects] index into transforms */
+    const int32_t* obj_interp;    /* [n_objects] Triangle::needInterpolate (raytracer.cpp:281) */
+    const double* obj_geom;       /* [n_objects][9] triangle: vertex1,vertex2,vertex3;
+                                     sphere: center[3], radius (a float value), 5 unused */
+    const double* obj_normals;    /* [n_objects][9] normal1..3 where obj_interp != 0; may be NULL
+                                     when no object interpolates */
+    const rt_material* materials;
+    const rt_transform* transforms;
+    const rt_light* lights;
+} rt_scene_desc;
+
+/* Options for rt_set_option. */
+typedef enum rt_option {
+    RT_OPT_EXACT_ONLY = 1,   /* 1: skip the FP32 candidate filter, test every primitive in
+                                reference precision (slow; used to validate the filter) */
+    RT_OPT_PROFILE = 2,      /* 1: bracket every trace-kernel launch with HIP events; the sums
+                                appear in rt_stats */
+    RT_OPT_PASS_PIXELS = 3,  /* pixels traced per internal pass (bounds the workspace) */
+    RT_OPT_USE_BVH = 4       /* 1: nearest hits through the LBVH instead of the brute-force scan */
+} rt_option;
+
+/* Counters since rt_upload_scene or the last rt_reset_stats. */
+typedef struct rt_stats {
+    uint64_t rays_primary;   /* traceRay calls from render() (raytracer.cpp:504) */
+    uint64_t rays_reflect;   /* recursive traceRay calls (raytracer.cpp:543) */
+    uint64_t rays_shadow;    /* traceShadowRay calls (raytracer.cpp:567) */
+    uint64_t hits;           /* traceRay calls that found an object */
+    uint64_t closest_tests;  /* ray x primitive pairs scanned by the nearest-hit kernel */
+    uint64_t anyhit_tests;   /* ray x primitive pairs scanned by the shadow kernel (nominal: no early out) */
+    uint64_t exact_tests;    /* candidate pairs re-evaluated in reference precision */
+    double closest_ms;       /* RT_OPT_PROFILE: summed duration of nearest-hit kernel launches */
+    double anyhit_ms;        /* RT_OPT_PROFILE: summed duration of shadow kernel launches */
+    uint32_t closest_launches, anyhit_launches;
+    int32_t n_triangles, n_spheres, n_groups, n_irregular;
+} rt_stats;
+
+typedef struct rt_ctx rt_ctx;
+
+/* Copy the scene to the current HIP device, precompute the per-primitive
+ * constants there and allocate the frame (width*height RGBA8) and the
+ * workspace.  Replaces nothing in the reference: it is the hand-over of the
+ * object graph built by parseSceneFile (raytracer.cpp:705) that
+ * Scene::render reads in place (raytracer.cpp:497). */
+int rt_upload_scene(rt_ctx** out, const rt_scene_desc* desc);
+
+int rt_set_option(rt_ctx* ctx, int option, int64_t value);
+
+/* Trace film rows [y0, y0+rows) -- y = 0 is the BOTTOM scanline, as in
+ * Sampler::generateSample / Camera::generateRay (raytracer.cpp:153, 441) --
+ * and store the quantised pixels (raytracer.cpp:174-203) into the frame.
+ * Asynchronous: work is enqueued on `stream` (a hipStream_t; NULL = the
+ * default stream).  Replaces the body of Scene::render for those rows
+ * (raytracer.cpp:502-511).  Calls on one ctx must not overlap. */
+int rt_render_tile(rt_ctx* ctx, int y0, int rows, void* stream);
+
+/* The interleaved form: tiles k = first_tile, first_tile+tile_step, ... where
+ * tile k is film rows [k*tile_rows, min((k+1)*tile_rows, height)); one rank of
+ * an N-GPU job calls it with first_tile = rank, tile_step = N. */
+int rt_render_tiles(rt_ctx* ctx, int first_tile, int tile_rows, int tile_step, void* stream);
+
+/* Use caller-owned device memory (width*height*4 bytes) as the frame, e.g. a
+ * tensor that a collective will read.  NULL returns to the internal frame. */
+int rt_bind_frame(rt_ctx* ctx, void* device_rgba, size_t bytes);
+
+/* Wait for the ctx's work and copy the whole frame to host memory in the
+ * layout Film::writeFile hands to lodepng::encode (raytracer.cpp:212-231):
+ * RGBA8, alpha 255, row 0 = TOP scanline (film row height-1).  Rows never
+ * rendered are black. */
+int rt_download(rt_ctx* ctx, uint8_t* rgba, size_t bytes);
+
+int rt_get_stats(rt_ctx* ctx, rt_stats* out);   /* waits for the ctx's work */
+int rt_reset_stats(rt_ctx* ctx);
+
+void rt_free(rt_ctx* ctx);
+
+const char* rt_last_error(void);
+
+/* Serialised scene description ("RTSD", little endian), written by the host
+ * loader (rth_save_scene) and by the reference-side binding; the layout is the
+ * field order of rt_scene_desc with the arrays inlined:
+ *   "RTSD", i32 version=1, i32 width, height, max_depth, f32 eps, shadow_eps,
+ *   i32 n_objects, n_materials, n_transforms, n_lights,
+ *   f64 cam_eye[3], cam_ll[3], cam_lr[3], cam_ul[3], cam_ur[3], ambient[3],
+ *   i32 obj_kind[n], obj_material[n], obj_transform[n], obj_interp[n],
+ *   (4 zero bytes if needed to reach a multiple of 8),
+ *   f64 obj_geom[n][9], obj_normals[n][9], rt_material[n_materials],
+ *   rt_transform[n_transforms], rt_light[n_lights].
+ */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_ABI_H */

@@ -1,0 +1,45 @@
+/* rt_host.h -- host-side companion of rt_abi.h (librt_host.so, no GPU code).
+ *
+ * A scene loader that accepts the reference's `.scene` / `.obj` grammar
+ * (parseSceneFile, raytracer.cpp:705-841; parseObj, raytracer.cpp:624-703;
+ * transform builders algebra3.h:1259-1299; mat4::inverse algebra3.h:1130-1161)
+ * and produces the flat rt_scene_desc that rt_upload_scene takes, plus the
+ * PNG writer standing where Film::writeFile calls lodepng::encode
+ * (raytracer.cpp:205-235).  The reference itself would not use this loader:
+ * it would flatten its own Scene object (INTEGRATION.md shows that binding).
+ */
+#ifndef RT_HOST_H
+#define RT_HOST_H
+
+#include "rt_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rth_scene rth_scene;   /* owns every array its rt_scene_desc points to */
+
+/* Parse `scene_path`.  `obj` file names are resolved against the scene file's
+ * directory (the reference resolves them against the cwd, raytracer.cpp:629,
+ * and is run from that directory).  max_depth < 0 selects the reference's 6
+ * (raytracer.cpp:477); eps <= 0 selects main's 0.05f (raytracer.cpp:849). */
+int rth_load_scene(rth_scene** out, const char* scene_path, int width, int height,
+                   int max_depth, float eps);
+
+/* Read / write the serialised "RTSD" form described in rt_abi.h. */
+int rth_load_blob(rth_scene** out, const char* blob_path);
+int rth_save_blob(const rth_scene* scene, const char* blob_path);
+
+const rt_scene_desc* rth_desc(const rth_scene* scene);
+void rth_free_scene(rth_scene* scene);
+
+/* Write an RGBA8 image whose row 0 is the top scanline -- the buffer
+ * rt_download fills -- as an 8-bit RGBA PNG. */
+int rth_write_png(const char* path, const uint8_t* rgba, int width, int height);
+
+const char* rth_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HOST_H */
