@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s (primary + shadow + reflect) on the teapot scene at 4K,
+depth 5, on N MI355X of one node.
+
+One process per GPU (torch.distributed over RCCL for N > 1).  A step is one full frame:
+every rank traces its interleaved 16-row scanline tiles through the C ABI
+(rt_render_tiles) and the tiles are gathered to rank 0.  Inputs (the uploaded scene) are
+resident in HBM before the timed region.  Rank 0 prints one JSON line.
+
+  roofline      the dominant kernel (nearest-hit or shadow scan, whichever took longer):
+                algorithmic FLOP = ray x primitive pairs scanned x 42 (triangle) or 28
+                (sphere), divided by the kernel's summed duration measured with HIP events
+                on the launch stream, against the 157.3 TFLOP/s FP32 vector peak.
+  cpu_baseline  the unmodified reference renderer (oracle/_ref, kind "reference") -- or the
+                C restatement when that binary is absent (kind "port") -- timed on this
+                box's host cores on a 1/16 x 1/16 sub-grid of the same frame.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_TRI, FLOP_SPH = 42.0, 28.0          # per ray-primitive test, FMA = 2
+PEAK_FP32_VALU = 157.3e12                # 256 CU x 128 lanes x 2 x 2.4 GHz
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "teapot.scene"))
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--depth", type=int, default=5)
+    ap.add_argument("--tile-rows", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exact-only", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, gpu_rays_fn):
+    """Times the reference CPU renderer on a bounded sample of the same workload: the frame
+    at 1/16 x 1/16 resolution, which is exactly every 16th pixel of the full grid in x and y
+    (the camera samples pixel corners: u = x / W)."""
+    w, h = max(1, args.width // 16), max(1, args.height // 16)
+    threads = min(16, os.cpu_count() or 1)
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_render")
+    rays = gpu_rays_fn(w, h)
+    if os.path.exists(ref):
+        out = subprocess.run([ref, args.scene, str(w), str(h), str(args.depth), "-", str(threads)],
+                             check=True, capture_output=True, text=True).stdout
+        secs = json.loads(out.strip().splitlines()[-1])["render_s"]
+        kind = "reference"
+    else:
+        from raytracer_amd import Scene
+        from tests import oracle_api
+        sc = Scene.load(args.scene, w, h, args.depth)
+        t0 = time.perf_counter()
+        oracle_api.Oracle().render(sc, threads=threads)
+        secs = time.perf_counter() - t0
+        kind = "port"
+    return {"value": rays / secs / 1e6, "unit": "Mrays/s", "cores": threads, "kind": kind,
+            "sample": f"{w}x{h} sub-grid (every 16th pixel in x and y) of the {args.width}x{args.height} frame, "
+                      f"{rays} rays, {secs:.2f} s"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd import Scene, abi
+    from raytracer_amd.render import Renderer, gather_frame
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    scene = Scene.load(args.scene, args.width, args.height, args.depth)
+    r = Renderer(scene)
+    if args.exact_only:
+        r.set_option(abi.RT_OPT_EXACT_ONLY, 1)
+    frame = torch.zeros((args.height, args.width, 4), dtype=torch.uint8, device=dev)
+    r.bind_frame(frame)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        r.render_tiles(rank, args.tile_rows, world, stream)
+        gather_frame(r, frame, args.tile_rows, rank, world, dist=dist, torch=torch)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    r.reset_stats()
+    r.set_option(abi.RT_OPT_PROFILE, 1)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    st = r.stats()
+    r.set_option(abi.RT_OPT_PROFILE, 0)
+
+    rays_local = st["rays_primary"] + st["rays_reflect"] + st["rays_shadow"]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        cnt = torch.tensor([rays_local, st["rays_primary"], st["rays_reflect"], st["rays_shadow"]],
+                           dtype=torch.int64, device=dev)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        rays_total, n_primary, n_reflect, n_shadow = [int(v) for v in cnt.tolist()]
+    else:
+        rays_total, n_primary, n_reflect, n_shadow = rays_local, st["rays_primary"], st["rays_reflect"], st["rays_shadow"]
+
+    if rank == 0:
+        n_tri, n_sph = st["n_triangles"], st["n_spheres"]
+        flop_per_test = (FLOP_TRI * n_tri + FLOP_SPH * n_sph) / max(1, n_tri + n_sph)
+        kernels = {"k_trace<0> (nearest hit)": (st["closest_ms"], st["closest_tests"], st["closest_launches"]),
+                   "k_trace<1> (shadow)": (st["anyhit_ms"], st["anyhit_tests"], st["anyhit_launches"])}
+        dom = max(kernels, key=lambda k: kernels[k][0])
+        ms, tests, launches = kernels[dom]
+        achieved = tests * flop_per_test / (ms * 1e-3) if ms > 0 else 0.0
+        both_ms = st["closest_ms"] + st["anyhit_ms"]
+        both = (st["closest_tests"] + st["anyhit_tests"]) * flop_per_test / (both_ms * 1e-3) if both_ms > 0 else 0.0
+        line = {
+            "metric": "Mrays/s (primary+shadow+reflect) teapot 4K depth-5",
+            "value": rays_total / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32 filter + f64/f32 reference-precision re-test",
+            "data": "synthetic (teapot.obj mesh + 2 floor triangles, authored scene file)",
+            "config": {"workload": f"{os.path.basename(args.scene)} {args.width}x{args.height} depth {args.depth}",
+                       "triangles": n_tri, "spheres": n_sph, "lights": scene.desc.n_lights,
+                       "tile_rows": args.tile_rows, "parallelism": f"interleaved scanline tiles x{world}",
+                       "rays_per_frame": {"primary": n_primary // args.steps, "reflect": n_reflect // args.steps,
+                                          "shadow": n_shadow // args.steps}},
+            "roofline": {"bound": "valu_fp32", "kernel": dom, "achieved": achieved / 1e12, "peak": PEAK_FP32_VALU / 1e12,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU, "traffic": None,
+                         "kernel_ms_avg": ms / max(1, launches), "launches": launches,
+                         "flop_per_test": flop_per_test, "tests_per_launch": tests / max(1, launches),
+                         "both_trace_kernels_tflops": both / 1e12,
+                         "exact_retests_per_ray": st["exact_tests"] / max(1, rays_local)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            def gpu_rays(w, h):
+                sc = Scene.load(args.scene, w, h, args.depth)
+                rr = Renderer(sc)
+                rr.render_frame()
+                s2 = rr.stats()
+                rr.close()
+                return s2["rays_primary"] + s2["rays_reflect"] + s2["rays_shadow"]
+            line["cpu_baseline"] = cpu_baseline(args, gpu_rays)
+        print(json.dumps(line), flush=True)
+    r.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,690 @@
+// C ABI of the MI355X trace loop (include/rt_abi.h): scene upload with the
+// per-primitive precomputation, the pass scheduler that strings the kernels of
+// rt_kernels.h together, download and statistics.
+#include "rt_abi.h"
+#include "rt_kernels.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+struct Vec { double x, y, z; };
+Vec vsub(Vec a, Vec b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+double vdot(Vec a, Vec b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+Vec vcross(Vec a, Vec b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+double vlen(Vec a) { return std::sqrt(vdot(a, a)); }
+
+// M * (p, 1) without the perspective divide: only used for bounds.
+Vec affine_point(const double* m, Vec p) {
+    return {m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
+            m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]};
+}
+Vec linear_dir(const double* m, Vec v) {
+    return {m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z,
+            m[8] * v.x + m[9] * v.y + m[10] * v.z};
+}
+
+struct Box {
+    double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+    void add(Vec p) {
+        double c[3] = {p.x, p.y, p.z};
+        for (int i = 0; i < 3; i++) {
+            if (c[i] < lo[i]) lo[i] = c[i];
+            if (c[i] > hi[i]) hi[i] = c[i];
+        }
+    }
+    Vec corner(int k) const { return {(k & 1) ? hi[0] : lo[0], (k & 2) ? hi[1] : lo[1], (k & 4) ? hi[2] : lo[2]}; }
+};
+
+double max_abs(Vec p) { return std::max(std::fabs(p.x), std::max(std::fabs(p.y), std::fabs(p.z))); }
+
+template <class T> struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        release();
+        n = count;
+        if (count == 0) return hipSuccess;
+        return hipMalloc((void**)&p, count * sizeof(T));
+    }
+    hipError_t upload(const std::vector<T>& v) {
+        hipError_t e = alloc(v.size());
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+    }
+};
+
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    int n_cu = 0;
+    DevScene hs{};                 // host copy (device pointers inside)
+    DevBuf<DevScene> d_scene;
+    DevBuf<v16f> tri_filt;
+    DevBuf<TriExact> tri_exact;
+    DevBuf<SphereRec> spheres;
+    DevBuf<Group> groups;
+    DevBuf<double> xforms;
+    DevBuf<int32_t> xf_identity, obj_kind, obj_slot, obj_material, obj_transform, obj_interp;
+    DevBuf<double> obj_geom, obj_normals;
+    DevBuf<DevMaterial> materials;
+    DevBuf<DevLight> lights;
+    DevBuf<uint32_t> own_frame;
+    uint32_t* frame = nullptr;     // own_frame.p or the caller's buffer
+    DevBuf<DevCounters> counters;
+
+    // workspace, sized for `cap` rays per pass
+    size_t cap = 0;
+    int levels = 0;                // max_depth + 1
+    int occl_words = 1;
+    DevBuf<double> rayq[2];        // [6][cap] each
+    DevBuf<unsigned long long> keys[2];
+    DevBuf<double> aux;            // [6][cap]
+    DevBuf<uint32_t> occluded;     // [cap][occl_words]
+    DevBuf<int32_t> pixel_of_ray;
+    DevBuf<int32_t> lvl_parent, lvl_obj;   // [levels][cap]
+    DevBuf<double> lvl_phong, lvl_child;   // [levels][3][cap]
+    DevBuf<uint32_t> counts;       // [levels + 1]
+
+    // options
+    int force_exact = 0;
+    int profile = 0;
+    long long pass_pixels = 4 << 20;
+
+    int trace_grid[2] = {0, 0};
+    int aux_grid = 0;
+    hipStream_t last_stream = nullptr;
+
+    struct Span { hipEvent_t a, b; int kind; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> event_pool;
+    double ms[2] = {0, 0};
+    unsigned launches[2] = {0, 0};
+};
+
+namespace {
+
+RayQueue queue_of(DevBuf<double>& b, size_t cap) {
+    RayQueue q;
+    q.ox = b.p; q.oy = b.p + cap; q.oz = b.p + 2 * cap;
+    q.dx = b.p + 3 * cap; q.dy = b.p + 4 * cap; q.dz = b.p + 5 * cap;
+    return q;
+}
+
+LevelStore level_of(rt_ctx* c, int k) {
+    LevelStore l;
+    l.parent = c->lvl_parent.p + (size_t)k * c->cap;
+    l.obj = c->lvl_obj.p + (size_t)k * c->cap;
+    l.phong = c->lvl_phong.p + (size_t)k * 3 * c->cap;
+    l.child = c->lvl_child.p + (size_t)k * 3 * c->cap;
+    return l;
+}
+
+int ensure_workspace(rt_ctx* c) {
+    size_t frame_px = (size_t)c->hs.width * c->hs.height;
+    size_t want = (size_t)std::min<long long>((long long)frame_px, std::max<long long>(c->pass_pixels, c->hs.width));
+    // whole rows per pass
+    want = std::max<size_t>(c->hs.width, want / c->hs.width * c->hs.width);
+    int levels = c->hs.max_depth + 1;
+    if (c->cap == want && c->levels == levels) return 0;
+    c->cap = want; c->levels = levels;
+    c->occl_words = std::max(1, (c->hs.n_lights + 31) / 32);
+    for (int i = 0; i < 2; i++) {
+        HIP_TRY(c->rayq[i].alloc(6 * want));
+        HIP_TRY(c->keys[i].alloc(want));
+    }
+    HIP_TRY(c->aux.alloc(6 * want));
+    HIP_TRY(c->occluded.alloc(want * c->occl_words));
+    HIP_TRY(c->pixel_of_ray.alloc(want));
+    HIP_TRY(c->lvl_parent.alloc((size_t)levels * want));
+    HIP_TRY(c->lvl_obj.alloc((size_t)levels * want));
+    HIP_TRY(c->lvl_phong.alloc((size_t)levels * 3 * want));
+    HIP_TRY(c->lvl_child.alloc((size_t)levels * 3 * want));
+    HIP_TRY(c->counts.alloc(levels + 2));
+    return 0;
+}
+
+hipEvent_t take_event(rt_ctx* c) {
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+// Resolve recorded spans into the running sums (requires their work to be finished).
+void drain_spans(rt_ctx* c) {
+    for (auto& s : c->spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            c->ms[s.kind] += ms;
+            c->launches[s.kind]++;
+        }
+        c->event_pool.push_back(s.a);
+        c->event_pool.push_back(s.b);
+    }
+    c->spans.clear();
+}
+
+template <int MODE>
+int launch_trace(rt_ctx* c, const TraceArgs& A, hipStream_t st) {
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (c->profile) {
+        ea = take_event(c); eb = take_event(c);
+        if (ea && eb) HIP_TRY(hipEventRecord(ea, st));
+    }
+    hipLaunchKernelGGL(k_trace<MODE>, dim3(c->trace_grid[MODE]), dim3(RT_BLOCK), 0, st,
+                       (const DevScene*)c->d_scene.p, (const v16f*)c->tri_filt.p, (const TriExact*)c->tri_exact.p, A);
+    HIP_TRY(hipGetLastError());
+    if (ea && eb) {
+        HIP_TRY(hipEventRecord(eb, st));
+        c->spans.push_back({ea, eb, MODE});
+    }
+    return 0;
+}
+
+// One pass: rows q0 .. q0+nrows of the pass's row sequence, nrows * width <= cap.
+int run_pass(rt_ctx* c, PassDesc pd, int nrows, hipStream_t st) {
+    const int W = c->hs.width;
+    const int n_pix = nrows * W;
+    const int levels = c->levels;
+    const DevScene* dsc = c->d_scene.p;
+    HIP_TRY(hipMemsetAsync(c->counts.p, 0, (levels + 2) * sizeof(uint32_t), st));
+    RayQueue q[2] = {queue_of(c->rayq[0], c->cap), queue_of(c->rayq[1], c->cap)};
+    hipLaunchKernelGGL(k_primary, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, dsc, pd, n_pix, q[0], c->keys[0].p,
+                       c->pixel_of_ray.p, c->frame, c->counts.p);
+    HIP_TRY(hipGetLastError());
+    HitAux aux;
+    aux.nx = c->aux.p; aux.ny = c->aux.p + c->cap; aux.nz = c->aux.p + 2 * c->cap;
+    aux.vx = c->aux.p + 3 * c->cap; aux.vy = c->aux.p + 4 * c->cap; aux.vz = c->aux.p + 5 * c->cap;
+    for (int k = 0; k < levels; k++) {
+        const int cur = k & 1, nxt = cur ^ 1;
+        LevelStore lvl = level_of(c, k);
+        TraceArgs ta{};
+        ta.rays = q[cur]; ta.n_items = c->counts.p + k; ta.keys = c->keys[cur].p;
+        ta.force_exact = c->force_exact; ta.counters = c->counters.p; ta.occl_words = c->occl_words;
+        int rc = launch_trace<0>(c, ta, st);
+        if (rc) return rc;
+
+        HitArgs ha{};
+        ha.sc = dsc; ha.cur = q[cur]; ha.next = q[nxt]; ha.keys = c->keys[cur].p; ha.next_keys = c->keys[nxt].p;
+        ha.n_rays = c->counts.p + k; ha.n_hits = c->counts.p + k + 1; ha.lvl = lvl; ha.aux = aux;
+        ha.occluded = c->occluded.p; ha.occl_words = c->occl_words;
+        hipLaunchKernelGGL(k_hit, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, ha);
+        HIP_TRY(hipGetLastError());
+
+        if (c->hs.n_lights > 0) {
+            TraceArgs sa{};
+            sa.rays = q[nxt]; sa.n_items = c->counts.p + k + 1; sa.source_obj = lvl.obj;
+            sa.occluded = c->occluded.p; sa.occl_words = c->occl_words;
+            sa.force_exact = c->force_exact; sa.counters = c->counters.p;
+            rc = launch_trace<1>(c, sa, st);
+            if (rc) return rc;
+        }
+
+        PhongArgs pa{};
+        pa.sc = dsc; pa.next = q[nxt]; pa.aux = aux; pa.lvl = lvl; pa.occluded = c->occluded.p;
+        pa.occl_words = c->occl_words; pa.cap = (uint32_t)c->cap; pa.n_hits = c->counts.p + k + 1;
+        hipLaunchKernelGGL(k_phong, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, pa);
+        HIP_TRY(hipGetLastError());
+    }
+    for (int k = levels - 1; k >= 0; k--) {
+        FoldArgs fa{};
+        fa.sc = dsc; fa.lvl = level_of(c, k); fa.parent_lvl = level_of(c, k > 0 ? k - 1 : 0);
+        fa.cap = (uint32_t)c->cap; fa.n_hits = c->counts.p + k + 1; fa.level = k;
+        fa.pixel_of_ray = c->pixel_of_ray.p; fa.frame = c->frame;
+        hipLaunchKernelGGL(k_fold, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, fa);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_count, dim3(1), dim3(64), 0, st, dsc, (const uint32_t*)c->counts.p, levels, c->counters.p);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Rows y_start + j*stride_rows + [0, tile_rows) for j = 0 .. n_tiles-1 (clipped to the frame).
+int render_rows(rt_ctx* c, int y_start, int tile_rows, int stride_rows, int n_tiles, hipStream_t st) {
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_workspace(c);
+    if (rc) return rc;
+    const int H = c->hs.height, W = c->hs.width;
+    // valid rows form a prefix of the pass's row sequence: only the last tile can be clipped
+    long long total_rows = 0;
+    for (int j = 0; j < n_tiles; j++) {
+        long long y0 = (long long)y_start + (long long)j * stride_rows;
+        if (y0 >= H) break;
+        total_rows += std::min<long long>(tile_rows, H - y0);
+    }
+    const int rows_per_pass = (int)(c->cap / W);
+    c->last_stream = st;
+    for (long long q0 = 0; q0 < total_rows; q0 += rows_per_pass) {
+        int nrows = (int)std::min<long long>(rows_per_pass, total_rows - q0);
+        PassDesc pd{y_start, tile_rows, stride_rows, (int)q0};
+        rc = run_pass(c, pd, nrows, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_err.c_str(); }
+
+int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
+    if (!out || !d) return fail(RT_ERR_ARG, "rt_upload_scene: null argument");
+    if (d->struct_size != sizeof(rt_scene_desc)) return fail(RT_ERR_ARG, "rt_upload_scene: struct_size mismatch");
+    if (d->width <= 0 || d->height <= 0 || d->max_depth < 0 || d->max_depth > 64)
+        return fail(RT_ERR_ARG, "rt_upload_scene: bad width/height/max_depth");
+    if ((long long)d->width * d->height > (1ll << 30)) return fail(RT_ERR_ARG, "rt_upload_scene: frame too large");
+    if (d->n_objects < 0 || d->n_lights < 0 || d->n_materials < 0 || d->n_transforms < 0)
+        return fail(RT_ERR_ARG, "rt_upload_scene: negative count");
+    const int N = d->n_objects;
+    if (N > 0 && (!d->obj_kind || !d->obj_material || !d->obj_transform || !d->obj_interp || !d->obj_geom ||
+                  !d->materials || !d->transforms))
+        return fail(RT_ERR_ARG, "rt_upload_scene: null object array");
+    if (d->n_lights > 0 && !d->lights) return fail(RT_ERR_ARG, "rt_upload_scene: null lights");
+    for (int i = 0; i < N; i++) {
+        if (d->obj_kind[i] != 0 && d->obj_kind[i] != 1) return fail(RT_ERR_ARG, "rt_upload_scene: bad obj_kind");
+        if (d->obj_material[i] < 0 || d->obj_material[i] >= d->n_materials)
+            return fail(RT_ERR_ARG, "rt_upload_scene: material index out of range");
+        if (d->obj_transform[i] < 0 || d->obj_transform[i] >= d->n_transforms)
+            return fail(RT_ERR_ARG, "rt_upload_scene: transform index out of range");
+        if (d->obj_interp[i] && !d->obj_normals) return fail(RT_ERR_ARG, "rt_upload_scene: obj_normals missing");
+    }
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(RT_ERR_DEVICE, "rt_upload_scene: no HIP device (the trace loop has no CPU fallback)");
+    rt_ctx* c = new rt_ctx();
+    auto bail = [&](int code) { rt_free(c); return code; };
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&c->device) != hipSuccess || hipGetDeviceProperties(&prop, c->device) != hipSuccess)
+        return bail(fail(RT_ERR_DEVICE, "rt_upload_scene: cannot query the current device"));
+    c->n_cu = prop.multiProcessorCount;
+
+    const int NX = d->n_transforms;
+    // ---- transforms ----
+    std::vector<double> xf(48 * (size_t)NX);
+    std::vector<int32_t> xf_ident(NX);
+    for (int t = 0; t < NX; t++) {
+        std::memcpy(&xf[48 * (size_t)t], d->transforms[t].m, 16 * 8);
+        std::memcpy(&xf[48 * (size_t)t + 16], d->transforms[t].inv, 16 * 8);
+        std::memcpy(&xf[48 * (size_t)t + 32], d->transforms[t].inv_t, 16 * 8);
+        int ident = 1;
+        for (int k = 0; k < 48; k++) {
+            double want = ((k % 16) % 5 == 0) ? 1.0 : 0.0;
+            if (std::memcmp(&xf[48 * (size_t)t + k], &want, 8) != 0) ident = 0;
+        }
+        xf_ident[t] = ident;
+    }
+
+    // ---- world bounds: every point a ray can start from ----
+    Box world;
+    world.add({d->cam_eye[0], d->cam_eye[1], d->cam_eye[2]});
+    double obj_extent = 0.0;   // largest |coordinate| of object-space geometry
+    for (int i = 0; i < N; i++) {
+        const double* g = d->obj_geom + 9 * (size_t)i;
+        const double* M = &xf[48 * (size_t)d->obj_transform[i]];
+        if (d->obj_kind[i] == 0) {
+            for (int k = 0; k < 3; k++) {
+                Vec v{g[3 * k], g[3 * k + 1], g[3 * k + 2]};
+                world.add(affine_point(M, v));
+                obj_extent = std::max(obj_extent, max_abs(v));
+            }
+        } else {
+            double r = std::fabs(g[3]);
+            for (int k = 0; k < 8; k++) {
+                Vec v{g[0] + ((k & 1) ? r : -r), g[1] + ((k & 2) ? r : -r), g[2] + ((k & 4) ? r : -r)};
+                world.add(affine_point(M, v));
+            }
+        }
+    }
+    double bound = obj_extent;
+    for (int k = 0; k < 8; k++) {
+        Vec w = world.corner(k);
+        bound = std::max(bound, max_abs(w));
+        for (int t = 0; t < NX; t++)
+            if (!xf_ident[t]) bound = std::max(bound, max_abs(affine_point(&xf[48 * (size_t)t + 16], w)));
+    }
+    if (!(bound < 1e30)) bound = 1e30;
+    const double origin_bound = bound * (1.0 + 1e-3) + 1e-3;
+    const double R = std::sqrt(3.0) * origin_bound;
+
+    // ---- direction bound: camera rays are unnormalised, later rays unit length in world space ----
+    double vmax = 1.0;
+    {
+        Vec eye{d->cam_eye[0], d->cam_eye[1], d->cam_eye[2]};
+        const double* corners[4] = {d->cam_ll, d->cam_lr, d->cam_ul, d->cam_ur};
+        for (int k = 0; k < 4; k++) {
+            Vec dir = vsub({corners[k][0], corners[k][1], corners[k][2]}, eye);
+            vmax = std::max(vmax, vlen(dir));
+            for (int t = 0; t < NX; t++)
+                if (!xf_ident[t]) vmax = std::max(vmax, vlen(linear_dir(&xf[48 * (size_t)t + 16], dir)));
+        }
+        for (int t = 0; t < NX; t++) {
+            if (xf_ident[t]) continue;
+            const double* I = &xf[48 * (size_t)t + 16];
+            double fro = 0;
+            for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) fro += I[4 * r + cc] * I[4 * r + cc];
+            vmax = std::max(vmax, std::sqrt(fro));
+        }
+        if (!(vmax < 1e15)) vmax = 1e15;
+        vmax *= 1.0 + 1e-3;
+    }
+
+    // ---- filter thresholds (error analysis in DESIGN.md; every constant is rounded up) ----
+    const double EPSF = 1.1920928955078125e-7;   // 2^-23
+    const double Eb = 8 * EPSF * vmax;
+    const double Ea = 16 * EPSF * R;
+    auto thresholds = [&](float eps) {
+        FilterParams f{};
+        double b_lo = (double)eps * (1 - 1e-3) - Eb;
+        double r_lo = (double)eps * (1 - 1e-3) - 4 * (Ea + (double)eps * Eb) / std::max(b_lo, 1e-30);
+        if (!(b_lo > 0)) { b_lo = 0; r_lo = -FLT_MAX; }      // filter degenerates to "keep everything grazing"
+        f.b_lo = (float)b_lo; f.r_lo = (float)r_lo; f.a_zero = (float)(2 * Ea);
+        return f;
+    };
+    const FilterParams fpc = thresholds(d->eps), fps = thresholds(d->shadow_eps);
+    const double b_lo_min = std::max(1e-30, (double)std::min(fpc.b_lo, fps.b_lo));
+    const double amp = 18.0 * vmax / b_lo_min + 17.0;          // position-error amplification of a grazing ray
+
+    // ---- triangles: reference-precision records, filter planes, regular / irregular split ----
+    struct TriTmp { TriExact ex; float4 f[4]; bool regular; int xf; };
+    std::vector<TriTmp> tris;
+    std::vector<SphereRec> sph;
+    std::vector<int32_t> slot(N, -1);
+    for (int i = 0; i < N; i++) {
+        const double* g = d->obj_geom + 9 * (size_t)i;
+        if (d->obj_kind[i] == 1) {
+            SphereRec s{};
+            s.c[0] = g[0]; s.c[1] = g[1]; s.c[2] = g[2];
+            float radius = (float)g[3];
+            s.r2 = (double)radius * (double)radius;
+            s.obj = i; s.xf = d->obj_transform[i]; s.identity = xf_ident[s.xf];
+            slot[i] = (int32_t)sph.size();
+            sph.push_back(s);
+            continue;
+        }
+        TriTmp t{};
+        t.xf = d->obj_transform[i];
+        Vec v1{g[0], g[1], g[2]}, v2{g[3], g[4], g[5]}, v3{g[6], g[7], g[8]};
+        Vec e1 = vsub(v3, v1), e2 = vsub(v2, v1);                  // raytracer.cpp:288-289
+        Vec cr = vcross(e2, e1);
+        double len = std::sqrt(cr.x * cr.x + cr.y * cr.y + cr.z * cr.z);
+        double inv = 1. / len;                                      // algebra3.h:638-662
+        Vec n{cr.x * inv, cr.y * inv, cr.z * inv};
+        float uu = (float)vdot(e1, e1), uv = (float)vdot(e1, e2), vv = (float)vdot(e2, e2);
+        float D = uv * uv - uu * vv;                                // raytracer.cpp:340 (float arithmetic)
+        TriExact& ex = t.ex;
+        ex.v1[0] = v1.x; ex.v1[1] = v1.y; ex.v1[2] = v1.z;
+        ex.e1[0] = e1.x; ex.e1[1] = e1.y; ex.e1[2] = e1.z;
+        ex.e2[0] = e2.x; ex.e2[1] = e2.y; ex.e2[2] = e2.z;
+        ex.n[0] = n.x; ex.n[1] = n.y; ex.n[2] = n.z;
+        ex.uu = uu; ex.uv = uv; ex.vv = vv; ex.D = D; ex.obj = i;
+        bool ok = std::isfinite(n.x) && std::isfinite(n.y) && std::isfinite(n.z) && std::isfinite(uu) &&
+                  std::isfinite(uv) && std::isfinite(vv) && std::isfinite(D) && D != 0.0f;
+        if (ok) {
+            // s = S.(x - v1), t = T.(x - v1) are the reference's barycentrics (raytracer.cpp:344, 348)
+            // as linear functions, built from ITS rounded uu, uv, vv, D.
+            double fuu = uu, fuv = uv, fvv = vv, fD = D;
+            Vec S{(fuv * e2.x - fvv * e1.x) / fD, (fuv * e2.y - fvv * e1.y) / fD, (fuv * e2.z - fvv * e1.z) / fD};
+            Vec T{(fuv * e1.x - fuu * e2.x) / fD, (fuv * e1.y - fuu * e2.y) / fD, (fuv * e1.z - fuu * e2.z) / fD};
+            double le1 = std::sqrt(fuu), le2 = std::sqrt(fvv);
+            double wmax = 1.5 * (le1 + le2);
+            // rounding of the reference's own float formula
+            double dBs = 2 * EPSF * wmax * (std::fabs(fuv) * le2 + fvv * le1) / std::fabs(fD) + 3 * EPSF;
+            double dBt = 2 * EPSF * wmax * (std::fabs(fuv) * le1 + fuu * le2) / std::fabs(fD) + 3 * EPSF;
+            // rounding of the FP32 filter itself (hit position and plane evaluation)
+            double dAs = EPSF * vlen(S) * R * amp, dAt = EPSF * vlen(T) * R * amp;
+            double ds = 4 * (dAs + dBs) + 1e-6, dt = 4 * (dAt + dBt) + 1e-6, du = ds + dt;
+            ok = std::isfinite(ds) && std::isfinite(dt) && dBs < 0.125 && dBt < 0.125 && du < 1e6;
+            if (ok) {
+                double d0 = vdot(n, v1);
+                double os = -vdot(S, v1) + ds, ot = -vdot(T, v1) + dt;
+                Vec U{-(S.x + T.x), -(S.y + T.y), -(S.z + T.z)};
+                double ou = 1.0 - vdot(U, v1) + du;
+                t.f[0] = make_float4((float)n.x, (float)n.y, (float)n.z, (float)d0);
+                t.f[1] = make_float4((float)S.x, (float)S.y, (float)S.z, (float)os);
+                t.f[2] = make_float4((float)T.x, (float)T.y, (float)T.z, (float)ot);
+                t.f[3] = make_float4((float)U.x, (float)U.y, (float)U.z, (float)ou);
+                for (int k = 0; k < 4; k++)
+                    ok = ok && std::isfinite(t.f[k].x) && std::isfinite(t.f[k].y) && std::isfinite(t.f[k].z) &&
+                         std::isfinite(t.f[k].w);
+            }
+        }
+        t.regular = ok;
+        tris.push_back(t);
+    }
+
+    // ---- order: regular triangles grouped by transform (stable), then the irregular ones likewise ----
+    std::vector<int> order_reg, order_irr;
+    for (int k = 0; k < (int)tris.size(); k++) (tris[k].regular ? order_reg : order_irr).push_back(k);
+    auto by_xf = [&](int a, int b) { return tris[a].xf < tris[b].xf; };
+    std::stable_sort(order_reg.begin(), order_reg.end(), by_xf);
+    std::stable_sort(order_irr.begin(), order_irr.end(), by_xf);
+    const int NR = (int)order_reg.size(), NI = (int)order_irr.size();
+    std::vector<v16f> filt((size_t)NR + 1);          // + one readable padding record
+    std::memset(filt.data(), 0, filt.size() * sizeof(v16f));
+    std::vector<TriExact> exact((size_t)NR + NI);
+    for (int k = 0; k < NR; k++) {
+        const TriTmp& t = tris[order_reg[k]];
+        for (int j = 0; j < 4; j++) {
+            filt[k][4 * j] = t.f[j].x; filt[k][4 * j + 1] = t.f[j].y;
+            filt[k][4 * j + 2] = t.f[j].z; filt[k][4 * j + 3] = t.f[j].w;
+        }
+        exact[k] = t.ex;
+        slot[t.ex.obj] = k;
+    }
+    for (int k = 0; k < NI; k++) {
+        const TriTmp& t = tris[order_irr[k]];
+        exact[(size_t)NR + k] = t.ex;
+        slot[t.ex.obj] = NR + k;
+    }
+    std::vector<Group> groups;
+    {
+        int r = 0, q = 0;
+        while (r < NR || q < NI) {
+            int xr = r < NR ? tris[order_reg[r]].xf : INT32_MAX;
+            int xq = q < NI ? tris[order_irr[q]].xf : INT32_MAX;
+            int x = std::min(xr, xq);
+            Group G{};
+            G.xf = x; G.identity = xf_ident[x];
+            G.fbeg = r;
+            while (r < NR && tris[order_reg[r]].xf == x) r++;
+            G.fend = r;
+            G.ibeg = NR + q;
+            while (q < NI && tris[order_irr[q]].xf == x) q++;
+            G.iend = NR + q;
+            groups.push_back(G);
+        }
+    }
+
+    std::vector<DevMaterial> mats(d->n_materials);
+    for (int i = 0; i < d->n_materials; i++) std::memcpy(&mats[i], &d->materials[i], sizeof(DevMaterial));
+    std::vector<DevLight> lights(d->n_lights);
+    for (int i = 0; i < d->n_lights; i++) std::memcpy(&lights[i], &d->lights[i], sizeof(DevLight));
+    static_assert(sizeof(DevMaterial) == sizeof(rt_material), "material layout");
+    static_assert(sizeof(DevLight) == sizeof(rt_light), "light layout");
+    static_assert(sizeof(TriExact) == 128, "TriExact layout");
+
+    std::vector<int32_t> kind(d->obj_kind, d->obj_kind + N), omat(d->obj_material, d->obj_material + N),
+        oxf(d->obj_transform, d->obj_transform + N), ointerp(d->obj_interp, d->obj_interp + N);
+    std::vector<double> geom(d->obj_geom, d->obj_geom + 9 * (size_t)N);
+    std::vector<double> nrm;
+    if (d->obj_normals) nrm.assign(d->obj_normals, d->obj_normals + 9 * (size_t)N);
+
+#define UP(buf, vec)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = c->buf.upload(vec);                                                            \
+        if (e_ != hipSuccess) return bail(fail(RT_ERR_DEVICE, std::string("upload " #buf ": ") + hipGetErrorString(e_))); \
+    } while (0)
+    UP(tri_filt, filt); UP(tri_exact, exact); UP(spheres, sph); UP(groups, groups); UP(xforms, xf);
+    UP(xf_identity, xf_ident); UP(obj_kind, kind); UP(obj_slot, slot); UP(obj_material, omat);
+    UP(obj_transform, oxf); UP(obj_interp, ointerp); UP(obj_geom, geom); UP(obj_normals, nrm);
+    UP(materials, mats); UP(lights, lights);
+#undef UP
+
+    DevScene& s = c->hs;
+    s.tri_filt = c->tri_filt.p; s.tri_exact = c->tri_exact.p; s.spheres = c->spheres.p; s.groups = c->groups.p;
+    s.xforms = c->xforms.p; s.xf_identity = c->xf_identity.p; s.obj_kind = c->obj_kind.p; s.obj_slot = c->obj_slot.p;
+    s.obj_material = c->obj_material.p; s.obj_transform = c->obj_transform.p; s.obj_interp = c->obj_interp.p;
+    s.obj_geom = c->obj_geom.p; s.obj_normals = c->obj_normals.p; s.materials = c->materials.p; s.lights = c->lights.p;
+    s.n_regular = NR; s.n_irregular = NI; s.n_spheres = (int)sph.size(); s.n_groups = (int)groups.size();
+    s.n_objects = N; s.n_lights = d->n_lights; s.n_transforms = NX;
+    s.last_xf = N > 0 ? d->obj_transform[N - 1] : 0;
+    s.width = d->width; s.height = d->height; s.max_depth = d->max_depth;
+    s.eps = d->eps; s.shadow_eps = d->shadow_eps;
+    s.origin_bound = (float)origin_bound;
+    s.dir_len2_bound = (float)(vmax * vmax);
+    s.fp_closest = fpc; s.fp_shadow = fps;
+    std::memcpy(s.cam_eye, d->cam_eye, 24); std::memcpy(s.cam_ll, d->cam_ll, 24); std::memcpy(s.cam_lr, d->cam_lr, 24);
+    std::memcpy(s.cam_ul, d->cam_ul, 24); std::memcpy(s.cam_ur, d->cam_ur, 24); std::memcpy(s.ambient, d->ambient, 24);
+    // the shading ray of an empty transform table cannot occur: N > 0 implies NX > 0
+
+    std::vector<DevScene> one(1, s);
+    hipError_t e = c->d_scene.upload(one);
+    if (e != hipSuccess) return bail(fail(RT_ERR_DEVICE, std::string("upload scene: ") + hipGetErrorString(e)));
+    e = c->own_frame.alloc((size_t)d->width * d->height);
+    if (e != hipSuccess) return bail(fail(RT_ERR_DEVICE, std::string("frame: ") + hipGetErrorString(e)));
+    c->frame = c->own_frame.p;
+    e = hipMemset(c->frame, 0, (size_t)d->width * d->height * 4);
+    if (e == hipSuccess) e = c->counters.alloc(1);
+    if (e == hipSuccess) e = hipMemset(c->counters.p, 0, sizeof(DevCounters));
+    if (e != hipSuccess) return bail(fail(RT_ERR_DEVICE, std::string("init: ") + hipGetErrorString(e)));
+
+    // launch geometry: as many resident blocks as the trace kernels admit
+    for (int m = 0; m < 2; m++) {
+        int nb = 0;
+        hipError_t oe = (m == 0)
+            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<0>, RT_BLOCK, 0)
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<1>, RT_BLOCK, 0);
+        if (oe != hipSuccess || nb < 1) nb = 2;
+        c->trace_grid[m] = c->n_cu * std::min(nb, 8);
+    }
+    c->aux_grid = c->n_cu * 8;
+    *out = c;
+    return 0;
+}
+
+int rt_set_option(rt_ctx* c, int option, int64_t value) {
+    if (!c) return fail(RT_ERR_ARG, "rt_set_option: null ctx");
+    switch (option) {
+        case RT_OPT_EXACT_ONLY: c->force_exact = value ? 1 : 0; return 0;
+        case RT_OPT_PROFILE: c->profile = value ? 1 : 0; return 0;
+        case RT_OPT_PASS_PIXELS:
+            if (value < 1) return fail(RT_ERR_ARG, "rt_set_option: pass pixels must be positive");
+            c->pass_pixels = value;
+            return 0;
+        case RT_OPT_USE_BVH: return value ? fail(RT_ERR_STATE, "rt_set_option: no BVH has been built") : 0;
+        default: return fail(RT_ERR_ARG, "rt_set_option: unknown option");
+    }
+}
+
+int rt_render_tile(rt_ctx* c, int y0, int rows, void* stream) {
+    if (!c) return fail(RT_ERR_ARG, "rt_render_tile: null ctx");
+    if (rows < 0 || y0 < 0 || (long long)y0 + rows > c->hs.height)
+        return fail(RT_ERR_RANGE, "rt_render_tile: rows outside the frame");
+    if (rows == 0) return 0;
+    return render_rows(c, y0, rows, rows, 1, (hipStream_t)stream);
+}
+
+int rt_render_tiles(rt_ctx* c, int first_tile, int tile_rows, int tile_step, void* stream) {
+    if (!c) return fail(RT_ERR_ARG, "rt_render_tiles: null ctx");
+    if (first_tile < 0 || tile_rows <= 0 || tile_step <= 0) return fail(RT_ERR_ARG, "rt_render_tiles: bad tiling");
+    const int n_total = (c->hs.height + tile_rows - 1) / tile_rows;
+    if (first_tile >= n_total) return 0;
+    const int n_mine = (n_total - first_tile + tile_step - 1) / tile_step;
+    return render_rows(c, first_tile * tile_rows, tile_rows, tile_step * tile_rows, n_mine, (hipStream_t)stream);
+}
+
+int rt_bind_frame(rt_ctx* c, void* device_rgba, size_t bytes) {
+    if (!c) return fail(RT_ERR_ARG, "rt_bind_frame: null ctx");
+    if (!device_rgba) { c->frame = c->own_frame.p; return 0; }
+    if (bytes < (size_t)c->hs.width * c->hs.height * 4) return fail(RT_ERR_RANGE, "rt_bind_frame: buffer too small");
+    if ((uintptr_t)device_rgba % 4) return fail(RT_ERR_ARG, "rt_bind_frame: buffer must be 4-byte aligned");
+    c->frame = (uint32_t*)device_rgba;
+    return 0;
+}
+
+int rt_download(rt_ctx* c, uint8_t* rgba, size_t bytes) {
+    if (!c || !rgba) return fail(RT_ERR_ARG, "rt_download: null argument");
+    const size_t need = (size_t)c->hs.width * c->hs.height * 4;
+    if (bytes < need) return fail(RT_ERR_RANGE, "rt_download: buffer too small");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->last_stream));
+    HIP_TRY(hipMemcpy(rgba, c->frame, need, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int rt_get_stats(rt_ctx* c, rt_stats* out) {
+    if (!c || !out) return fail(RT_ERR_ARG, "rt_get_stats: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->last_stream));
+    drain_spans(c);
+    DevCounters dc;
+    HIP_TRY(hipMemcpy(&dc, c->counters.p, sizeof dc, hipMemcpyDeviceToHost));
+    std::memset(out, 0, sizeof *out);
+    out->rays_primary = dc.rays_primary; out->rays_reflect = dc.rays_reflect; out->rays_shadow = dc.rays_shadow;
+    out->hits = dc.hits; out->closest_tests = dc.closest_tests; out->anyhit_tests = dc.anyhit_tests;
+    out->exact_tests = dc.exact_tests;
+    out->closest_ms = c->ms[0]; out->anyhit_ms = c->ms[1];
+    out->closest_launches = c->launches[0]; out->anyhit_launches = c->launches[1];
+    out->n_triangles = c->hs.n_regular + c->hs.n_irregular; out->n_spheres = c->hs.n_spheres;
+    out->n_groups = c->hs.n_groups; out->n_irregular = c->hs.n_irregular;
+    return 0;
+}
+
+int rt_reset_stats(rt_ctx* c) {
+    if (!c) return fail(RT_ERR_ARG, "rt_reset_stats: null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->last_stream));
+    drain_spans(c);
+    c->ms[0] = c->ms[1] = 0; c->launches[0] = c->launches[1] = 0;
+    HIP_TRY(hipMemset(c->counters.p, 0, sizeof(DevCounters)));
+    return 0;
+}
+
+void rt_free(rt_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto& s : c->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    c->d_scene.release(); c->tri_filt.release(); c->tri_exact.release(); c->spheres.release(); c->groups.release();
+    c->xforms.release(); c->xf_identity.release(); c->obj_kind.release(); c->obj_slot.release();
+    c->obj_material.release(); c->obj_transform.release(); c->obj_interp.release(); c->obj_geom.release();
+    c->obj_normals.release(); c->materials.release(); c->lights.release(); c->own_frame.release();
+    c->counters.release();
+    for (int i = 0; i < 2; i++) { c->rayq[i].release(); c->keys[i].release(); }
+    c->aux.release(); c->occluded.release(); c->pixel_of_ray.release(); c->lvl_parent.release();
+    c->lvl_obj.release(); c->lvl_phong.release(); c->lvl_child.release(); c->counts.release();
+    delete c;
+}
+
+}  // extern "C"

@@ -1,0 +1,181 @@
+// Device-side scene layout and the reference-precision ("exact") primitive
+// routines.  Everything here keeps the reference's evaluation order and its
+// double -> float rounding points (raytracer.cpp:312-357, 393-414, 32-34);
+// the translation unit is built with -ffp-contract=off so nothing is fused.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RT_MISS_T 3.402823466e+38f          // MAXFLOAT: the reference's miss sentinel
+#define RT_MISS_KEY 0x7f7fffffffffffffull   // (bits(MAXFLOAT) << 32) | 0xffffffff
+
+struct d3 { double x, y, z; };
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(4))) const v16f cv16f;
+
+// Regular triangle, FP32 filter form: four float4 per triangle
+//   [0] unit normal n, plane offset d0 = n.v1
+//   [1..3] the barycentric coordinates s, t and u = 1-s-t as affine functions of a
+//          point, each with its safety margin folded into the offset.
+// Reference-precision form of the same triangle (128 bytes):
+struct __attribute__((aligned(16))) TriExact {
+    double v1[3];      // vertex1
+    double e1[3];      // edge1 = vertex3 - vertex1 (raytracer.cpp:288)
+    double e2[3];      // edge2 = vertex2 - vertex1 (raytracer.cpp:289)
+    double n[3];       // (edge2 ^ edge1).normalize() (raytracer.cpp:313)
+    float uu, uv, vv, D;   // raytracer.cpp:334-340, each rounded as the reference does
+    int32_t obj;       // index in Scene::objects
+    int32_t pad[3];
+};
+
+struct __attribute__((aligned(16))) SphereRec {
+    double c[3];
+    double r2;         // (double)radius * (double)radius, pow(radius, 2) at raytracer.cpp:396
+    int32_t obj, xf, identity, pad;
+};
+
+// Triangles that share one transform.  Filter slots [fbeg, fend) are regular
+// triangles; exact slots [ibeg, iend) hold the group's irregular triangles
+// (degenerate, non-finite, or too ill-conditioned for the FP32 filter), which
+// are always tested in reference precision.
+struct Group {
+    int32_t xf, identity;
+    int32_t fbeg, fend;
+    int32_t ibeg, iend;
+    int32_t pad[2];
+};
+
+struct DevMaterial { double ka[3], kd[3], ks[3], kr[3]; double sp; };
+struct DevLight { double color[3], pos[3]; int32_t falloff, is_point; };
+
+// Thresholds of the FP32 candidate filter for one kind of query (nearest hit
+// uses Scene::eps, shadow rays 0.1f).  A pair (ray, triangle) may be dropped
+// only when the reference-precision test is certain to miss.
+struct FilterParams {
+    float b_lo;      // |n.dir| below this: the reference's grazing reject is certain
+    float r_lo;      // ray parameter below this: the reference's r < eps reject is certain
+    float a_zero;    // |plane distance of the origin| at or below this: a == 0.0f is possible
+    float pad;
+};
+
+struct DevScene {
+    const v16f* tri_filt;        // [n_regular + 1]: one padding record at the end
+    const TriExact* tri_exact;
+    const SphereRec* spheres;
+    const Group* groups;
+    const double* xforms;        // [n_transforms][48]: M, inverse, inverse-transpose (row-major)
+    const int32_t* xf_identity;  // [n_transforms] 1 when M is bit-for-bit the identity
+    const int32_t* obj_kind;
+    const int32_t* obj_slot;     // triangle: slot in tri_exact; sphere: slot in spheres
+    const int32_t* obj_material;
+    const int32_t* obj_transform;
+    const int32_t* obj_interp;
+    const double* obj_geom;
+    const double* obj_normals;
+    const DevMaterial* materials;
+    const DevLight* lights;
+    int32_t n_regular, n_irregular, n_spheres, n_groups;
+    int32_t n_objects, n_lights, n_transforms, last_xf;
+    int32_t width, height, max_depth, pad0;
+    float eps, shadow_eps;
+    float origin_bound;          // filter trusted only for |origin component| <= this
+    float dir_len2_bound;        // ... and |dir|^2 <= this
+    FilterParams fp_closest, fp_shadow;
+    double cam_eye[3], cam_ll[3], cam_lr[3], cam_ul[3], cam_ur[3];
+    double ambient[3];
+};
+
+// ---- double-precision vector helpers (same operation order as algebra3.h) ----
+__device__ __forceinline__ d3 mk3(double x, double y, double z) { d3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ d3 ld3(const double* p) { return mk3(p[0], p[1], p[2]); }
+__device__ __forceinline__ d3 add3(d3 a, d3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ d3 sub3(d3 a, d3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ d3 neg3(d3 a) { return mk3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ d3 scl3(d3 a, double d) { return mk3(d * a.x, d * a.y, d * a.z); }
+__device__ __forceinline__ d3 mul3(d3 a, d3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ double dot3(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ d3 cross3(d3 a, d3 b) {
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// vec3::normalize multiplies by 1/length (algebra3.h:638-662)
+__device__ __forceinline__ d3 nrm3(d3 a) {
+    double len = sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
+    double inv = 1. / len;
+    return mk3(a.x * inv, a.y * inv, a.z * inv);
+}
+// float distance(vec3&, vec3&) (raytracer.cpp:32-34)
+__device__ __forceinline__ float dist_f(d3 a, d3 b) {
+    double dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    return (float)sqrt(dx * dx + dy * dy + dz * dz);
+}
+// vec3(M * vec4(p, 1)): the vec3 constructor divides by w (algebra3.h:853, 610)
+__device__ __forceinline__ d3 xf_point(const double* m, d3 p) {
+    double o0 = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3] * 1.0;
+    double o1 = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7] * 1.0;
+    double o2 = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11] * 1.0;
+    double o3 = m[12] * p.x + m[13] * p.y + m[14] * p.z + m[15] * 1.0;
+    return mk3(o0 / o3, o1 / o3, o2 / o3);
+}
+// vec3(M * vec4(v, 0), VW): w dropped (algebra3.h:614-621)
+__device__ __forceinline__ d3 xf_dir(const double* m, d3 v) {
+    double o0 = m[0] * v.x + m[1] * v.y + m[2] * v.z + m[3] * 0.0;
+    double o1 = m[4] * v.x + m[5] * v.y + m[6] * v.z + m[7] * 0.0;
+    double o2 = m[8] * v.x + m[9] * v.y + m[10] * v.z + m[11] * 0.0;
+    return mk3(o0, o1, o2);
+}
+
+// Triangle::intersection (raytracer.cpp:312-357) on a precomputed record.
+__device__ __forceinline__ float tri_intersect_exact(const TriExact& T, d3 pos, d3 vec, float eps) {
+    d3 v1 = ld3(T.v1), e1 = ld3(T.e1), e2 = ld3(T.e2), nrm = ld3(T.n);
+    d3 w0 = sub3(pos, v1);
+    float a = (float)(-dot3(nrm, w0));
+    float b = (float)dot3(nrm, vec);
+    float r = a / b;
+    if (fabsf(b) < eps) {
+        return (a == 0.0f) ? r : RT_MISS_T;
+    }
+    if (r < 0.0f) return RT_MISS_T;
+    d3 isect = add3(pos, scl3(vec, (double)r));
+    d3 w = sub3(isect, v1);
+    float wu = (float)dot3(w, e1);
+    float wv = (float)dot3(w, e2);
+    float s = (T.uv * wv - T.vv * wu) / T.D;
+    if (s < 0.0f || s > 1.0f) return RT_MISS_T;
+    float t = (T.uv * wu - T.uu * wv) / T.D;
+    if (t < 0.0f || (s + t) > 1.0f) return RT_MISS_T;
+    if (r < eps) return RT_MISS_T;
+    return r;
+}
+
+// Sphere::intersection (raytracer.cpp:393-414).
+__device__ __forceinline__ float sph_intersect_exact(const SphereRec& S, d3 pos, d3 vec, float eps) {
+    d3 pc = sub3(pos, ld3(S.c));
+    double dpc = dot3(vec, pc);
+    double dd = dot3(vec, vec);
+    float disc = (float)(dpc * dpc - (dd * (dot3(pc, pc) - S.r2)));
+    if (disc < 0) return RT_MISS_T;
+    float sq = sqrtf(disc);
+    double mdpc = dot3(neg3(vec), pc);
+    float t1 = (float)((mdpc + (double)sq) / dd);
+    float t2 = (float)((mdpc - (double)sq) / dd);
+    if (t1 < eps && t2 < eps) return RT_MISS_T;
+    d3 p1 = add3(pos, scl3(vec, (double)t1));
+    d3 p2 = add3(pos, scl3(vec, (double)t2));
+    float d1 = dist_f(pos, p1), d2 = dist_f(pos, p2);
+    return d1 < d2 ? t1 : t2;
+}
+
+// The nearest-hit metric of Scene::traceRay (raytracer.cpp:522-524): distance
+// from the OBJECT-space origin to the WORLD-space hit point.
+__device__ __forceinline__ float hit_metric(const double* m, int identity, d3 rpos, d3 rvec, float t, d3* world) {
+    d3 p = add3(rpos, scl3(rvec, (double)t));
+    if (!identity) p = xf_point(m, p);
+    *world = p;
+    return dist_f(rpos, p);
+}
+
+__device__ __forceinline__ unsigned long long make_key(float d, int obj) {
+    return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)obj;
+}

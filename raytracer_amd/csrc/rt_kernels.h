@@ -1,0 +1,523 @@
+// The trace loop as a wavefront pipeline.  One "level" is one generation of
+// rays (level 0 = camera rays, level k = k-th reflection).  Per level:
+//   k_closest  nearest hit of every ray in the level's queue (brute force)
+//   k_hit      compacts the rays that hit something (ballot + one atomic per
+//              wave), computes hit point, normal and reflection, and writes
+//              the next level's ray queue
+//   k_anyhit   one shadow ray per (hit, light)
+//   k_phong    Phong sum over the unshadowed lights
+// and after the last level k_fold walks the levels deepest-first to evaluate
+//   phong_0 + kr_0 * (phong_1 + kr_1 * (...))            (raytracer.cpp:542-543)
+// in the reference's order.  Queue lengths live in device memory; nothing
+// is read back by the host between kernels.
+//
+// k_closest / k_anyhit scan every primitive for every ray.  Regular triangles
+// go through an FP32 filter (16 floats per triangle, wave-uniform, so the
+// compiler fetches them with scalar loads and they never occupy vector
+// registers); pairs the filter cannot rule out are queued per lane in LDS and
+// re-evaluated in the reference's mixed double/float arithmetic, so every
+// accept/reject decision and every hit distance is the reference's own.
+#pragma once
+
+#include "rt_device.h"
+
+#define RT_BLOCK 256
+#define RT_WAVE 64
+#define RT_CAND_CAP 48          // per-lane candidate slots in LDS
+#define RT_BATCH 16             // triangles filtered between two capacity checks
+#define RT_CHUNK 32768          // candidate indices are stored relative to a chunk base (u16)
+
+struct RayQueue {               // structure of arrays, one entry per ray
+    double *ox, *oy, *oz, *dx, *dy, *dz;
+};
+
+struct LevelStore {             // one entry per hit of a level
+    int32_t* parent;            // index of the ray in this level's queue (= hit index one level up, or the pixel)
+    int32_t* obj;               // Scene::objects index that was hit
+    double* phong;              // [3][cap] phongShade result
+    double* child;              // [3][cap] value returned by the reflected ray (0 when it misses)
+};
+
+struct HitAux {                 // per hit of the current level only
+    double *nx, *ny, *nz;       // shading normal
+    double *vx, *vy, *vz;       // the last object's transformed ray direction (raytracer.cpp:518-520)
+};
+
+struct PassDesc {               // rows traced by one pass, see rt_render_tiles
+    int32_t y_start, tile_rows, stride_rows, q0;   // pass row q -> y = y_start + (q / tile_rows) * stride_rows + q % tile_rows
+};
+
+struct DevCounters {
+    unsigned long long rays_primary, rays_reflect, rays_shadow, hits;
+    unsigned long long closest_tests, anyhit_tests, exact_tests;
+};
+
+// ---------------------------------------------------------------------------
+// Camera::generateRay (raytracer.cpp:441-447) for the pixels of a pass, plus the
+// black background of pixels whose ray hits nothing (raytracer.cpp:546).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(RT_BLOCK)
+k_primary(const DevScene* __restrict__ sc, PassDesc pd, int n_pix, RayQueue q,
+          unsigned long long* __restrict__ keys, int32_t* __restrict__ pixel_of_ray,
+          uint32_t* __restrict__ frame, uint32_t* __restrict__ counts) {
+    int W = sc->width, H = sc->height;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n_pix; p += gridDim.x * blockDim.x) {
+        int qrow = pd.q0 + p / W, x = p % W;
+        int y = pd.y_start + (qrow / pd.tile_rows) * pd.stride_rows + qrow % pd.tile_rows;
+        float u = (float)x / (float)W;
+        float v = (float)y / (float)H;
+        d3 ll = ld3(sc->cam_ll), lr = ld3(sc->cam_lr), ul = ld3(sc->cam_ul), ur = ld3(sc->cam_ur);
+        d3 bottom = add3(scl3(ll, (double)(1 - u)), scl3(lr, (double)u));
+        d3 top = add3(scl3(ul, (double)(1 - u)), scl3(ur, (double)u));
+        d3 c = add3(scl3(bottom, (double)(1 - v)), scl3(top, (double)v));
+        d3 eye = ld3(sc->cam_eye);
+        d3 dir = sub3(c, eye);
+        q.ox[p] = eye.x; q.oy[p] = eye.y; q.oz[p] = eye.z;
+        q.dx[p] = dir.x; q.dy[p] = dir.y; q.dz[p] = dir.z;
+        keys[p] = RT_MISS_KEY;
+        int pix = (H - 1 - y) * W + x;          // row 0 of the frame is the top scanline (raytracer.cpp:225)
+        pixel_of_ray[p] = pix;
+        frame[pix] = 0xff000000u;               // R,G,B = 0, alpha = 255
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) counts[0] = (uint32_t)n_pix;
+}
+
+// ---------------------------------------------------------------------------
+// Brute-force scan.  MODE 0: nearest hit; MODE 1: any hit (shadow).
+// ---------------------------------------------------------------------------
+struct TraceArgs {
+    RayQueue rays;                       // MODE 0: the level's rays.  MODE 1: origins = hit points
+    const uint32_t* n_items;             // MODE 0: number of rays; MODE 1: number of hits (shadow rays = hits * n_lights)
+    unsigned long long* keys;            // MODE 0: per ray, atomicMin of (metric bits, object index)
+    const int32_t* source_obj;           // MODE 1: object each hit lies on (excluded, raytracer.cpp:553)
+    uint32_t* occluded;                  // MODE 1: per hit, one bit per light
+    int32_t occl_words;                  // MODE 1: 32-bit words per hit
+    int32_t force_exact;                 // 1: bypass the FP32 filter
+    DevCounters* counters;
+};
+
+// Candidate test in reference precision and bookkeeping of the winner.
+template <int MODE>
+struct LaneState {
+    d3 pos, vec;                         // the ray in the current group's object space
+    float best_d; int best_obj;          // MODE 0
+    int source; bool done;               // MODE 1
+    unsigned int n_exact;
+};
+
+template <int MODE>
+__device__ __forceinline__ void exact_tri(LaneState<MODE>& L, const TriExact& T, const double* M, int identity, float eps) {
+    float t = tri_intersect_exact(T, L.pos, L.vec, eps);
+    L.n_exact++;
+    if (MODE == 0) {
+        d3 world;
+        float d = hit_metric(M, identity, L.pos, L.vec, t, &world);
+        // raytracer.cpp:525: t != MAXFLOAT && d < min_dist; ties keep the lower index
+        if (t != RT_MISS_T && (d < L.best_d || (d == L.best_d && T.obj < L.best_obj && L.best_obj >= 0))) {
+            L.best_d = d; L.best_obj = T.obj;
+        }
+    } else {
+        if (t != RT_MISS_T && T.obj != L.source) L.done = true;    // raytracer.cpp:553 (NaN != MAXFLOAT is true)
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void exact_sphere(LaneState<MODE>& L, const SphereRec& S, d3 pos, d3 vec,
+                                             const double* M, int identity, float eps) {
+    float t = sph_intersect_exact(S, pos, vec, eps);
+    L.n_exact++;
+    if (MODE == 0) {
+        d3 world;
+        float d = hit_metric(M, identity, pos, vec, t, &world);
+        if (t != RT_MISS_T && (d < L.best_d || (d == L.best_d && S.obj < L.best_obj && L.best_obj >= 0))) {
+            L.best_d = d; L.best_obj = S.obj;
+        }
+    } else {
+        if (t != RT_MISS_T && S.obj != L.source) L.done = true;
+    }
+}
+
+// The FP32 filter: false only when the reference-precision test of this (ray, triangle)
+// pair is certain to miss.  f = {n, d0 | S, s0 | T, t0 | U, u0}: the triangle's plane and its
+// three barycentric coordinates as affine functions with their margins folded in.
+// 24 vector instructions; the triangle's 16 floats arrive in scalar registers.
+__device__ __forceinline__ bool filter_keep(const v16f f, float px, float py, float pz, float vx, float vy, float vz,
+                                            const FilterParams fp) {
+    float b = f[0] * vx;
+    b = __builtin_fmaf(f[1], vy, b);
+    b = __builtin_fmaf(f[2], vz, b);
+    float a = __builtin_fmaf(-f[0], px, f[3]);
+    a = __builtin_fmaf(-f[1], py, a);
+    a = __builtin_fmaf(-f[2], pz, a);
+    const float r = a * __builtin_amdgcn_rcpf(b);
+    const float hx = __builtin_fmaf(r, vx, px);
+    const float hy = __builtin_fmaf(r, vy, py);
+    const float hz = __builtin_fmaf(r, vz, pz);
+    const float s = __builtin_fmaf(f[4], hx, __builtin_fmaf(f[5], hy, __builtin_fmaf(f[6], hz, f[7])));
+    const float t = __builtin_fmaf(f[8], hx, __builtin_fmaf(f[9], hy, __builtin_fmaf(f[10], hz, f[11])));
+    const float u = __builtin_fmaf(f[12], hx, __builtin_fmaf(f[13], hy, __builtin_fmaf(f[14], hz, f[15])));
+    const float m = __builtin_fminf(__builtin_fminf(s, t), u);
+    // Every comparison is false for NaN, so NaN never rejects.
+    const bool reject = (m < 0.0f) | (r < fp.r_lo) | (fabsf(b) < fp.b_lo);
+    return (!reject) | (fabsf(a) <= fp.a_zero);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(RT_BLOCK)
+k_trace(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, const TriExact* __restrict__ exact,
+        TraceArgs A) {
+    // The filter records are never written while a kernel runs: reading them through the
+    // constant address space lets the compiler use scalar loads (s_load_dwordx16).
+    const cv16f* filt = (const cv16f*)filt_global;
+    __shared__ unsigned short cand[RT_CAND_CAP * RT_BLOCK];
+    const int lane = threadIdx.x & (RT_WAVE - 1);
+    // threadIdx.x / 64 is the same in every lane of a wave; say so, so that everything
+    // derived from it (task, triangle index) stays in scalar registers.
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / RT_WAVE);
+    unsigned short* my_cand = cand + wave_in_block * RT_WAVE + lane;   // entry k at my_cand[k * RT_BLOCK]
+    const int n_waves = gridDim.x * (RT_BLOCK / RT_WAVE);
+    const int wave_id = blockIdx.x * (RT_BLOCK / RT_WAVE) + wave_in_block;
+
+    const int n_lights = sc->n_lights;
+    // the queue length is the same for every lane: keep it (and all loop bounds derived from it) scalar
+    const unsigned int n_hits = __builtin_amdgcn_readfirstlane(*A.n_items);
+    const unsigned long long n_rays = (MODE == 0) ? n_hits : (unsigned long long)n_hits * n_lights;
+    const unsigned int n_ray_blocks = (unsigned int)((n_rays + RT_WAVE - 1) / RT_WAVE);
+    const int NR = sc->n_regular;
+    // Split the triangle range over several waves when there are too few rays to fill the chip.
+    int max_split = (NR + 2047) / 2048;
+    if (max_split < 1) max_split = 1;
+    int split = 1;
+    if (n_ray_blocks > 0 && n_ray_blocks < 2u * n_waves) {
+        split = (2 * n_waves + n_ray_blocks - 1) / n_ray_blocks;
+        if (split > max_split) split = max_split;
+    }
+    const unsigned long long n_tasks = (unsigned long long)n_ray_blocks * split;
+    const float eps = (MODE == 0) ? sc->eps : sc->shadow_eps;
+    const FilterParams fp = (MODE == 0) ? sc->fp_closest : sc->fp_shadow;
+    unsigned int exact_total = 0;
+
+    for (unsigned long long task = wave_id; task < n_tasks; task += n_waves) {
+        const unsigned int rb = (unsigned int)(task % n_ray_blocks);
+        const int part = (int)(task / n_ray_blocks);
+        const unsigned long long ray = (unsigned long long)rb * RT_WAVE + lane;
+        const bool valid = ray < n_rays;
+        LaneState<MODE> L;
+        L.best_d = RT_MISS_T; L.best_obj = -1; L.source = -1; L.done = !valid; L.n_exact = 0;
+        d3 wpos = mk3(0, 0, 0), wvec = mk3(0, 0, 1);
+        unsigned int hit_index = 0, light_index = 0;
+        if (valid) {
+            if (MODE == 0) {
+                wpos = mk3(A.rays.ox[ray], A.rays.oy[ray], A.rays.oz[ray]);
+                wvec = mk3(A.rays.dx[ray], A.rays.dy[ray], A.rays.dz[ray]);
+            } else {
+                hit_index = (unsigned int)(ray / n_lights);
+                light_index = (unsigned int)(ray % n_lights);
+                wpos = mk3(A.rays.ox[hit_index], A.rays.oy[hit_index], A.rays.oz[hit_index]);
+                const DevLight& lt = sc->lights[light_index];
+                // Light::lightRay (raytracer.cpp:108-119)
+                d3 lv = lt.is_point ? sub3(ld3(lt.pos), wpos) : neg3(ld3(lt.pos));
+                wvec = nrm3(lv);
+                L.source = A.source_obj[hit_index];
+            }
+        }
+
+        // ---- spheres and irregular triangles: always in reference precision (first part only) ----
+        if (part == 0) {
+            for (int s = 0; s < sc->n_spheres; s++) {
+                const SphereRec& S = sc->spheres[s];
+                const double* X = sc->xforms + 48 * (size_t)S.xf;
+                d3 pos = wpos, vec = wvec;
+                int ident = 1;
+                if (MODE == 0 && !S.identity) {       // shadow rays are never transformed (raytracer.cpp:553)
+                    pos = xf_point(X + 16, wpos); vec = xf_dir(X + 16, wvec); ident = 0;
+                }
+                if (!L.done) exact_sphere<MODE>(L, S, pos, vec, X, ident, eps);
+            }
+        }
+
+        // ---- triangles, group by group ----
+        const int n_groups = (MODE == 0) ? sc->n_groups : 1;
+        for (int g = 0; g < n_groups; g++) {
+            int fbeg, fend, ibeg, iend, ident = 1;
+            const double* X = sc->xforms;
+            if (MODE == 0) {
+                const Group& G = sc->groups[g];
+                fbeg = G.fbeg; fend = G.fend; ibeg = G.ibeg; iend = G.iend; ident = G.identity;
+                X = sc->xforms + 48 * (size_t)G.xf;
+                if (ident) { L.pos = wpos; L.vec = wvec; }
+                else { L.pos = xf_point(X + 16, wpos); L.vec = xf_dir(X + 16, wvec); }   // transformRay, raytracer.cpp:251
+            } else {
+                fbeg = 0; fend = NR; ibeg = NR; iend = NR + sc->n_irregular;
+                L.pos = wpos; L.vec = wvec;
+            }
+            if (part == 0) {
+                for (int i = ibeg; i < iend; i++)
+                    if (!L.done) exact_tri<MODE>(L, exact[i], X, ident, eps);
+            }
+            // this wave's share of the group's regular triangles
+            const int glen = fend - fbeg;
+            const int pbeg = fbeg + (int)(((long long)glen * part) / split);
+            const int pend = fbeg + (int)(((long long)glen * (part + 1)) / split);
+
+            const float px = (float)L.pos.x, py = (float)L.pos.y, pz = (float)L.pos.z;
+            const float vx = (float)L.vec.x, vy = (float)L.vec.y, vz = (float)L.vec.z;
+            // Outside the bounds the margins were derived for (or NaN): test everything exactly.
+            const float ob = sc->origin_bound;
+            bool trusted = fabsf(px) <= ob && fabsf(py) <= ob && fabsf(pz) <= ob &&
+                           (vx * vx + vy * vy + vz * vz) <= sc->dir_len2_bound;
+            const bool force = A.force_exact || !trusted;
+
+            for (int cbeg = pbeg; cbeg < pend; cbeg += RT_CHUNK) {
+                const int cend = min(cbeg + RT_CHUNK, pend);
+                int n_cand = 0;
+                for (int j0 = cbeg; j0 < cend; j0 += RT_BATCH) {
+                    const int jn = min(j0 + RT_BATCH, cend);
+                    if (MODE == 1 && !__any(!L.done)) break;
+                    // The record of triangle j+1 is requested before triangle j is evaluated
+                    // (the array carries one padding record, so j+1 is always readable).
+                    v16f cur = filt[j0];
+#pragma unroll 2
+                    for (int j = j0; j < jn; j++) {
+                        const v16f nxt = filt[j + 1];
+                        const bool c = filter_keep(cur, px, py, pz, vx, vy, vz, fp) | force;
+                        if (c && !L.done) {
+                            my_cand[n_cand * RT_BLOCK] = (unsigned short)(j - cbeg);
+                            n_cand++;
+                        }
+                        cur = nxt;
+                    }
+                    // Drain when some lane could overflow during the next batch, and at the end of the chunk.
+                    const bool last = jn >= cend;
+                    if (__any(n_cand > RT_CAND_CAP - RT_BATCH) || (last && __any(n_cand > 0))) {
+                        for (int k = 0; __any(k < n_cand); k++) {
+                            if (k < n_cand && !L.done) {
+                                const int j = cbeg + my_cand[k * RT_BLOCK];
+                                exact_tri<MODE>(L, exact[j], X, ident, eps);
+                            }
+                        }
+                        n_cand = 0;
+                    }
+                }
+            }
+        }
+
+        // ---- publish ----
+        if (valid) {
+            if (MODE == 0) {
+                if (L.best_obj >= 0) atomicMin(&A.keys[ray], make_key(L.best_d, L.best_obj));
+            } else if (L.done) {
+                atomicOr(&A.occluded[(size_t)hit_index * A.occl_words + (light_index >> 5)], 1u << (light_index & 31));
+            }
+        }
+        exact_total += L.n_exact;
+    }
+    // one counter update per wave
+    for (int off = 32; off > 0; off >>= 1) exact_total += __shfl_xor(exact_total, off);
+    if (lane == 0 && exact_total) atomicAdd(&A.counters->exact_tests, (unsigned long long)exact_total);
+}
+
+// ---------------------------------------------------------------------------
+// After k_closest: the part of Scene::traceRay behind the object loop
+// (raytracer.cpp:531-538) for every ray that hit, compacted.
+// ---------------------------------------------------------------------------
+struct HitArgs {
+    const DevScene* sc;
+    RayQueue cur, next;                  // next[h] = (hit point, reflected direction)
+    const unsigned long long* keys;
+    unsigned long long* next_keys;
+    const uint32_t* n_rays;
+    uint32_t* n_hits;                    // zeroed by the host before the launch
+    LevelStore lvl;
+    HitAux aux;
+    uint32_t* occluded;
+    int32_t occl_words;
+};
+
+__global__ void __launch_bounds__(RT_BLOCK)
+k_hit(HitArgs A) {
+    const DevScene* __restrict__ sc = A.sc;
+    const unsigned int n = *A.n_rays;
+    const int lane = threadIdx.x & (RT_WAVE - 1);
+    const unsigned int stride = gridDim.x * blockDim.x;
+    const unsigned int n_round = (n + stride - 1) / stride * stride;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+        unsigned long long key = (i < n) ? A.keys[i] : RT_MISS_KEY;
+        const bool hit = key != RT_MISS_KEY;
+        // wave-level compaction: one atomic per wave
+        const unsigned long long ballot = __ballot(hit);
+        unsigned int base = 0;
+        if (lane == 0 && ballot) base = atomicAdd(A.n_hits, (unsigned int)__popcll(ballot));
+        base = __shfl(base, 0);
+        if (!hit) continue;
+        const unsigned int h = base + (unsigned int)__popcll(ballot & ((1ull << lane) - 1ull));
+        const int obj = (int)(unsigned int)(key & 0xffffffffu);
+        const int xf = sc->obj_transform[obj];
+        const double* X = sc->xforms + 48 * (size_t)xf;
+        const int ident = sc->xf_identity[xf];
+        d3 wpos = mk3(A.cur.ox[i], A.cur.oy[i], A.cur.oz[i]);
+        d3 wvec = mk3(A.cur.dx[i], A.cur.dy[i], A.cur.dz[i]);
+        d3 rpos = wpos, rvec = wvec;
+        if (!ident) { rpos = xf_point(X + 16, wpos); rvec = xf_dir(X + 16, wvec); }
+        const int slot = sc->obj_slot[obj];
+        float t;
+        d3 nobj;
+        d3 point;
+        if (sc->obj_kind[obj] == 0) {
+            const TriExact& T = sc->tri_exact[slot];
+            t = tri_intersect_exact(T, rpos, rvec, sc->eps);
+            hit_metric(X, ident, rpos, rvec, t, &point);
+            d3 local = ident ? point : xf_point(X + 16, point);      // inverseTransform * minIntersection (raytracer.cpp:533)
+            if (sc->obj_interp[obj]) {
+                // Triangle::normal, interpolated (raytracer.cpp:360-369)
+                const double* g = sc->obj_geom + 9 * (size_t)obj;
+                const double* nn = sc->obj_normals + 9 * (size_t)obj;
+                d3 v1 = ld3(g), v2 = ld3(g + 3), v3 = ld3(g + 6);
+                d3 fn = ld3(T.n);
+                float a1 = (float)dot3(fn, cross3(sub3(v2, v1), sub3(v3, v1)));
+                float a2 = (float)dot3(fn, cross3(sub3(v2, local), sub3(v3, local)));
+                float a3 = (float)dot3(fn, cross3(sub3(v3, local), sub3(v1, local)));
+                float alpha = a2 / a1;
+                float beta = a3 / a1;
+                float gamma = 1.0f - alpha - beta;
+                nobj = add3(add3(scl3(ld3(nn), (double)alpha), scl3(ld3(nn + 3), (double)beta)),
+                            scl3(ld3(nn + 6), (double)gamma));
+            } else {
+                nobj = cross3(ld3(T.e2), ld3(T.e1));                 // raytracer.cpp:371
+            }
+        } else {
+            const SphereRec& S = sc->spheres[slot];
+            t = sph_intersect_exact(S, rpos, rvec, sc->eps);
+            hit_metric(X, ident, rpos, rvec, t, &point);
+            d3 local = ident ? point : xf_point(X + 16, point);
+            nobj = sub3(local, ld3(S.c));                            // Sphere::normal (raytracer.cpp:416)
+        }
+        d3 nw = ident ? nobj : xf_dir(X + 32, nobj);                 // transformNormal (raytracer.cpp:260-266)
+        nw = nrm3(nw);
+        // `ray` after the object loop is the LAST object's transformed ray (raytracer.cpp:518-520, 536)
+        d3 rv = wvec;
+        if (!sc->xf_identity[sc->last_xf]) rv = xf_dir(sc->xforms + 48 * (size_t)sc->last_xf + 16, wvec);
+        d3 refl = sub3(rv, scl3(nw, 2 * dot3(rv, nw)));
+        refl = nrm3(refl);
+        A.next.ox[h] = point.x; A.next.oy[h] = point.y; A.next.oz[h] = point.z;
+        A.next.dx[h] = refl.x; A.next.dy[h] = refl.y; A.next.dz[h] = refl.z;
+        A.next_keys[h] = RT_MISS_KEY;
+        A.aux.nx[h] = nw.x; A.aux.ny[h] = nw.y; A.aux.nz[h] = nw.z;
+        A.aux.vx[h] = rv.x; A.aux.vy[h] = rv.y; A.aux.vz[h] = rv.z;
+        A.lvl.parent[h] = (int32_t)i;
+        A.lvl.obj[h] = obj;
+        for (int w = 0; w < A.occl_words; w++) A.occluded[(size_t)h * A.occl_words + w] = 0u;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Scene::phongShade (raytracer.cpp:560-581) given the shadow results.
+// ---------------------------------------------------------------------------
+struct PhongArgs {
+    const DevScene* sc;
+    RayQueue next;                       // origins = hit points
+    HitAux aux;
+    LevelStore lvl;
+    const uint32_t* occluded;
+    int32_t occl_words;
+    uint32_t cap;                        // stride of lvl.phong / lvl.child component planes
+    const uint32_t* n_hits;
+};
+
+__global__ void __launch_bounds__(RT_BLOCK)
+k_phong(PhongArgs A) {
+    const DevScene* __restrict__ sc = A.sc;
+    const unsigned int n = *A.n_hits;
+    for (unsigned int h = blockIdx.x * blockDim.x + threadIdx.x; h < n; h += gridDim.x * blockDim.x) {
+        const DevMaterial& m = sc->materials[sc->obj_material[A.lvl.obj[h]]];
+        d3 point = mk3(A.next.ox[h], A.next.oy[h], A.next.oz[h]);
+        d3 normal = mk3(A.aux.nx[h], A.aux.ny[h], A.aux.nz[h]);
+        d3 rayvec = mk3(A.aux.vx[h], A.aux.vy[h], A.aux.vz[h]);
+        d3 total = mk3(0, 0, 0);
+        total = add3(total, mul3(ld3(sc->ambient), ld3(m.ka)));
+        for (int i = 0; i < sc->n_lights; i++) {
+            if ((A.occluded[(size_t)h * A.occl_words + (i >> 5)] >> (i & 31)) & 1u) continue;
+            const DevLight& lt = sc->lights[i];
+            d3 lpos = ld3(lt.pos), color = ld3(lt.color);
+            d3 intensity = color;
+            if (lt.falloff != 0) {                       // Light::intensityAt (raytracer.cpp:121-128)
+                float d = dist_f(lpos, point);
+                double dd = (double)d;
+                double p = lt.falloff == 1 ? dd : (lt.falloff == 2 ? dd * dd : pow(dd, (double)lt.falloff));
+                double inv = 1. / p;
+                intensity = mk3(color.x * inv, color.y * inv, color.z * inv);
+            }
+            d3 l = lt.is_point ? sub3(lpos, point) : neg3(lpos);
+            d3 v = neg3(rayvec);
+            d3 r = add3(neg3(l), scl3(normal, 2 * dot3(l, normal)));
+            l = nrm3(l); v = nrm3(v); r = nrm3(r);
+            double ln = dot3(l, normal), rv = dot3(r, v);
+            double diff = ln > 0.0f ? ln : 0.0f;          // MAX(l * normal, 0.0f) (algebra3.h:34)
+            double sbase = rv > 0.0f ? rv : 0.0f;
+            double spec = pow(sbase, m.sp);
+            d3 coeffs = add3(scl3(ld3(m.kd), diff), scl3(ld3(m.ks), spec));
+            total = add3(total, mul3(intensity, coeffs));
+        }
+        A.lvl.phong[h] = total.x; A.lvl.phong[h + (size_t)A.cap] = total.y; A.lvl.phong[h + 2 * (size_t)A.cap] = total.z;
+        A.lvl.child[h] = 0.0; A.lvl.child[h + (size_t)A.cap] = 0.0; A.lvl.child[h + 2 * (size_t)A.cap] = 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// One step of the deepest-first fold.  For level k > 0 the value goes into the
+// parent hit's `child`; for level 0 it is quantised into the frame
+// (floatToByte / writeToFilm / the uchar store, raytracer.cpp:174-203, 225).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t quantise(double c) {
+    double scaled = c * 255.0f;
+    int v = (scaled >= -2147483648.0 && scaled < 2147483648.0) ? (int)scaled : (-2147483647 - 1);
+    if (v > 255) v = 255;
+    return (uint32_t)(v & 0xff);
+}
+
+struct FoldArgs {
+    const DevScene* sc;
+    LevelStore lvl, parent_lvl;
+    uint32_t cap;
+    const uint32_t* n_hits;
+    int32_t level;
+    const int32_t* pixel_of_ray;
+    uint32_t* frame;
+};
+
+__global__ void __launch_bounds__(RT_BLOCK)
+k_fold(FoldArgs A) {
+    const DevScene* __restrict__ sc = A.sc;
+    const unsigned int n = *A.n_hits;
+    const size_t cap = A.cap;
+    for (unsigned int h = blockIdx.x * blockDim.x + threadIdx.x; h < n; h += gridDim.x * blockDim.x) {
+        const DevMaterial& m = sc->materials[sc->obj_material[A.lvl.obj[h]]];
+        d3 phong = mk3(A.lvl.phong[h], A.lvl.phong[h + cap], A.lvl.phong[h + 2 * cap]);
+        d3 child = mk3(A.lvl.child[h], A.lvl.child[h + cap], A.lvl.child[h + 2 * cap]);
+        d3 val = add3(phong, mul3(child, ld3(m.kr)));     // raytracer.cpp:542-543
+        const int parent = A.lvl.parent[h];
+        if (A.level > 0) {
+            A.parent_lvl.child[parent] = val.x;
+            A.parent_lvl.child[parent + cap] = val.y;
+            A.parent_lvl.child[parent + 2 * cap] = val.z;
+        } else {
+            A.frame[A.pixel_of_ray[parent]] =
+                quantise(val.x) | (quantise(val.y) << 8) | (quantise(val.z) << 16) | 0xff000000u;
+        }
+    }
+}
+
+// Adds one pass's queue lengths to the running counters.
+__global__ void k_count(const DevScene* __restrict__ sc, const uint32_t* __restrict__ counts, int levels,
+                        DevCounters* __restrict__ c) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    unsigned long long prims = (unsigned long long)sc->n_regular + sc->n_irregular + sc->n_spheres;
+    unsigned long long rays = 0, hits = 0;
+    for (int k = 0; k < levels; k++) { rays += counts[k]; hits += counts[k + 1]; }
+    c->rays_primary += counts[0];
+    c->rays_reflect += rays - counts[0];
+    c->rays_shadow += hits * (unsigned long long)sc->n_lights;
+    c->hits += hits;
+    c->closest_tests += rays * prims;
+    c->anyhit_tests += hits * (unsigned long long)sc->n_lights * prims;
+}

@@ -1,0 +1,127 @@
+"""Device-side renderer handle over libraytracer_amd.so (the C ABI of include/rt_abi.h)
+and the one-process-per-GPU tile driver.
+
+The Python layer is plumbing only: it owns no arithmetic of the trace loop.
+Every pixel comes out of rt_render_tile / rt_render_tiles.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from .scene import Scene
+
+
+class DeviceError(RuntimeError):
+    pass
+
+
+def _check(lib, rc, what):
+    if rc != 0:
+        raise DeviceError(f"{what} failed ({rc}): {lib.rt_last_error().decode()}")
+
+
+class Renderer:
+    """One rt_ctx on the current HIP device.
+
+    Stands where the reference calls scene->render() (raytracer.cpp:857):
+    construct from a parsed Scene, render rows or interleaved tiles, download
+    the RGBA8 frame that Film::writeFile would hand to lodepng.
+    """
+
+    def __init__(self, scene: Scene):
+        self._lib = abi.device_lib()
+        self._ctx = C.c_void_p()
+        self.width, self.height = scene.width, scene.height
+        _check(self._lib, self._lib.rt_upload_scene(C.byref(self._ctx), scene.desc_ptr), "rt_upload_scene")
+        self._bound = None
+
+    def set_option(self, option, value):
+        _check(self._lib, self._lib.rt_set_option(self._ctx, int(option), int(value)), "rt_set_option")
+
+    def render_tile(self, y0, rows, stream=None):
+        _check(self._lib, self._lib.rt_render_tile(self._ctx, int(y0), int(rows), C.c_void_p(stream or 0)),
+               "rt_render_tile")
+
+    def render_tiles(self, first_tile, tile_rows, tile_step, stream=None):
+        _check(self._lib, self._lib.rt_render_tiles(self._ctx, int(first_tile), int(tile_rows), int(tile_step),
+                                                    C.c_void_p(stream or 0)), "rt_render_tiles")
+
+    def render_frame(self, stream=None):
+        self.render_tile(0, self.height, stream)
+
+    def bind_frame(self, tensor):
+        """Use a torch uint8 CUDA tensor of height*width*4 bytes as the frame."""
+        if tensor is None:
+            _check(self._lib, self._lib.rt_bind_frame(self._ctx, None, 0), "rt_bind_frame")
+            self._bound = None
+            return
+        nbytes = tensor.numel() * tensor.element_size()
+        _check(self._lib, self._lib.rt_bind_frame(self._ctx, C.c_void_p(tensor.data_ptr()), nbytes), "rt_bind_frame")
+        self._bound = tensor   # keep it alive
+
+    def download(self):
+        out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        _check(self._lib, self._lib.rt_download(self._ctx, out.ctypes.data_as(C.c_void_p), out.nbytes), "rt_download")
+        return out
+
+    def stats(self):
+        st = abi.RtStats()
+        _check(self._lib, self._lib.rt_get_stats(self._ctx, C.byref(st)), "rt_get_stats")
+        return st.as_dict()
+
+    def reset_stats(self):
+        _check(self._lib, self._lib.rt_reset_stats(self._ctx), "rt_reset_stats")
+
+    def close(self):
+        if self._ctx:
+            self._lib.rt_free(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def tiles_of_rank(height, tile_rows, rank, world):
+    """Film-row ranges [y0, y1) of the interleaved scanline tiles owned by `rank`:
+    tile k covers rows [k*tile_rows, (k+1)*tile_rows) and belongs to rank k % world."""
+    n_tiles = (height + tile_rows - 1) // tile_rows
+    return [(k * tile_rows, min((k + 1) * tile_rows, height)) for k in range(rank, n_tiles, world)]
+
+
+def pack_rows(frame, height, tile_rows, rank, world):
+    """Gather the rows a rank rendered into one contiguous buffer (frame is [H, W, 4],
+    row 0 = top scanline, so film row y is frame row H-1-y).  Works on numpy arrays and
+    torch tensors alike; every rank's buffer is padded to the same number of rows."""
+    n_tiles = (height + tile_rows - 1) // tile_rows
+    max_tiles = (n_tiles + world - 1) // world
+    rows = []
+    for y0, y1 in tiles_of_rank(height, tile_rows, rank, world):
+        rows.extend(range(height - 1 - y0, height - 1 - y1, -1))
+    return rows, max_tiles * tile_rows
+
+
+def gather_frame(renderer, frame, tile_rows, rank, world, dist=None, torch=None):
+    """End-of-frame exchange: every rank sends the rows of its tiles to rank 0, which
+    writes them into its frame.  `frame` is the rank's bound [H, W, 4] uint8 tensor;
+    the collective is torch.distributed.gather (RCCL on GPUs, gloo on CPU)."""
+    H, W = frame.shape[0], frame.shape[1]
+    rows, padded = pack_rows(frame, H, tile_rows, rank, world)
+    idx = torch.as_tensor(rows, dtype=torch.long, device=frame.device)
+    send = torch.zeros((padded, W, 4), dtype=torch.uint8, device=frame.device)
+    if len(rows):
+        send[: len(rows)] = frame.index_select(0, idx)
+    if world == 1:
+        return frame
+    recv = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+    dist.gather(send, recv, dst=0)
+    if rank == 0:
+        for r in range(1, world):
+            rrows, _ = pack_rows(frame, H, tile_rows, r, world)
+            if rrows:
+                ridx = torch.as_tensor(rrows, dtype=torch.long, device=frame.device)
+                frame.index_copy_(0, ridx, recv[r][: len(rrows)])
+    return frame
