@@ -198,7 +198,7 @@ int launch_trace(rt_ctx* c, const TraceArgs& A, hipStream_t st) {
         ea = take_event(c); eb = take_event(c);
         if (ea && eb) HIP_TRY(hipEventRecord(ea, st));
     }
-    hipLaunchKernelGGL(k_trace<MODE>, dim3(c->trace_grid[MODE]), dim3(RT_BLOCK), 0, st,
+    hipLaunchKernelGGL((k_trace<MODE, RT_RPL>), dim3(c->trace_grid[MODE]), dim3(RT_BLOCK), 0, st,
                        (const DevScene*)c->d_scene.p, (const v16f*)c->tri_filt.p, (const TriExact*)c->tri_exact.p, A);
     HIP_TRY(hipGetLastError());
     if (ea && eb) {
@@ -582,8 +582,8 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
     for (int m = 0; m < 2; m++) {
         int nb = 0;
         hipError_t oe = (m == 0)
-            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<0>, RT_BLOCK, 0)
-            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<1>, RT_BLOCK, 0);
+            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<0, RT_RPL>, RT_BLOCK, 0)
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<1, RT_RPL>, RT_BLOCK, 0);
         if (oe != hipSuccess || nb < 1) nb = 2;
         c->trace_grid[m] = c->n_cu * std::min(nb, 8);
     }

@@ -23,9 +23,10 @@
 
 #define RT_BLOCK 256
 #define RT_WAVE 64
-#define RT_CAND_CAP 48          // per-lane candidate slots in LDS
+#define RT_CAND_CAP 48          // per-lane candidate slots in LDS (shared by the lane's rays)
 #define RT_BATCH 16             // triangles filtered between two capacity checks
-#define RT_CHUNK 32768          // candidate indices are stored relative to a chunk base (u16)
+#define RT_CHUNK 32768          // candidate = 15-bit triangle index relative to a chunk base + ray slot in bit 15
+#define RT_RPL 2                // rays per lane in the trace kernels
 
 struct RayQueue {               // structure of arrays, one entry per ray
     double *ox, *oy, *oz, *dx, *dy, *dz;
@@ -96,51 +97,56 @@ struct TraceArgs {
     DevCounters* counters;
 };
 
-// Candidate test in reference precision and bookkeeping of the winner.
+// World-space ray number `ray` of a launch.  MODE 0: entry `ray` of the level's queue.
+// MODE 1: shadow ray of hit ray / n_lights towards light ray % n_lights (Light::lightRay,
+// raytracer.cpp:108-119); *source = the object the hit lies on.
 template <int MODE>
-struct LaneState {
-    d3 pos, vec;                         // the ray in the current group's object space
-    float best_d; int best_obj;          // MODE 0
-    int source; bool done;               // MODE 1
-    unsigned int n_exact;
-};
-
-template <int MODE>
-__device__ __forceinline__ void exact_tri(LaneState<MODE>& L, const TriExact& T, const double* M, int identity, float eps) {
-    float t = tri_intersect_exact(T, L.pos, L.vec, eps);
-    L.n_exact++;
+__device__ __forceinline__ void load_world_ray(const TraceArgs& A, const DevScene* __restrict__ sc,
+                                               unsigned long long ray, int n_lights, d3* pos, d3* vec, int* source) {
     if (MODE == 0) {
-        d3 world;
-        float d = hit_metric(M, identity, L.pos, L.vec, t, &world);
-        // raytracer.cpp:525: t != MAXFLOAT && d < min_dist; ties keep the lower index
-        if (t != RT_MISS_T && (d < L.best_d || (d == L.best_d && T.obj < L.best_obj && L.best_obj >= 0))) {
-            L.best_d = d; L.best_obj = T.obj;
-        }
+        *pos = mk3(A.rays.ox[ray], A.rays.oy[ray], A.rays.oz[ray]);
+        *vec = mk3(A.rays.dx[ray], A.rays.dy[ray], A.rays.dz[ray]);
+        *source = -1;
     } else {
-        if (t != RT_MISS_T && T.obj != L.source) L.done = true;    // raytracer.cpp:553 (NaN != MAXFLOAT is true)
+        const unsigned int hit = (unsigned int)(ray / n_lights), light = (unsigned int)(ray % n_lights);
+        *pos = mk3(A.rays.ox[hit], A.rays.oy[hit], A.rays.oz[hit]);
+        const DevLight& lt = sc->lights[light];
+        d3 lv = lt.is_point ? sub3(ld3(lt.pos), *pos) : neg3(ld3(lt.pos));
+        *vec = nrm3(lv);
+        *source = A.source_obj[hit];
     }
 }
 
+// Polygon::transformRay (raytracer.cpp:251-259); X = {M, M^-1, M^-T}.
+__device__ __forceinline__ void to_object_space(const double* X, int identity, d3* pos, d3* vec) {
+    if (!identity) {
+        d3 p = xf_point(X + 16, *pos), v = xf_dir(X + 16, *vec);
+        *pos = p; *vec = v;
+    }
+}
+
+// One primitive tested in reference precision; folds the result into the ray's running
+// answer.  MODE 0: (metric, object) with the reference's strict '<' and lowest-index tie
+// rule (raytracer.cpp:525).  MODE 1: any hit other than the source (raytracer.cpp:553;
+// a NaN result counts as a hit there because NaN != MAXFLOAT).
 template <int MODE>
-__device__ __forceinline__ void exact_sphere(LaneState<MODE>& L, const SphereRec& S, d3 pos, d3 vec,
-                                             const double* M, int identity, float eps) {
-    float t = sph_intersect_exact(S, pos, vec, eps);
-    L.n_exact++;
+__device__ __forceinline__ void fold_result(float t, int obj, d3 pos, d3 vec, const double* X, int identity,
+                                            int source, float* best_d, int* best_obj, bool* occluded) {
     if (MODE == 0) {
         d3 world;
-        float d = hit_metric(M, identity, pos, vec, t, &world);
-        if (t != RT_MISS_T && (d < L.best_d || (d == L.best_d && S.obj < L.best_obj && L.best_obj >= 0))) {
-            L.best_d = d; L.best_obj = S.obj;
+        float d = hit_metric(X, identity, pos, vec, t, &world);
+        if (t != RT_MISS_T && (d < *best_d || (d == *best_d && *best_obj >= 0 && obj < *best_obj))) {
+            *best_d = d; *best_obj = obj;
         }
     } else {
-        if (t != RT_MISS_T && S.obj != L.source) L.done = true;
+        if (t != RT_MISS_T && obj != source) *occluded = true;
     }
 }
 
 // The FP32 filter: false only when the reference-precision test of this (ray, triangle)
 // pair is certain to miss.  f = {n, d0 | S, s0 | T, t0 | U, u0}: the triangle's plane and its
 // three barycentric coordinates as affine functions with their margins folded in.
-// 24 vector instructions; the triangle's 16 floats arrive in scalar registers.
+// The triangle's 16 floats arrive in scalar registers.
 __device__ __forceinline__ bool filter_keep(const v16f f, float px, float py, float pz, float vx, float vy, float vz,
                                             const FilterParams fp) {
     float b = f[0] * vx;
@@ -157,12 +163,14 @@ __device__ __forceinline__ bool filter_keep(const v16f f, float px, float py, fl
     const float t = __builtin_fmaf(f[8], hx, __builtin_fmaf(f[9], hy, __builtin_fmaf(f[10], hz, f[11])));
     const float u = __builtin_fmaf(f[12], hx, __builtin_fmaf(f[13], hy, __builtin_fmaf(f[14], hz, f[15])));
     const float m = __builtin_fminf(__builtin_fminf(s, t), u);
-    // Every comparison is false for NaN, so NaN never rejects.
-    const bool reject = (m < 0.0f) | (r < fp.r_lo) | (fabsf(b) < fp.b_lo);
+    // Every comparison is false for NaN, so NaN never rejects.  A ray too parallel to the
+    // plane (|b| below the reference's grazing threshold) needs no test of its own: the
+    // reference then misses unless the origin lies on the plane, which the last term keeps.
+    const bool reject = (m < 0.0f) | (r < fp.r_lo);
     return (!reject) | (fabsf(a) <= fp.a_zero);
 }
 
-template <int MODE>
+template <int MODE, int RPL>
 __global__ void __launch_bounds__(RT_BLOCK)
 k_trace(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, const TriExact* __restrict__ exact,
         TraceArgs A) {
@@ -177,13 +185,14 @@ k_trace(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, c
     unsigned short* my_cand = cand + wave_in_block * RT_WAVE + lane;   // entry k at my_cand[k * RT_BLOCK]
     const int n_waves = gridDim.x * (RT_BLOCK / RT_WAVE);
     const int wave_id = blockIdx.x * (RT_BLOCK / RT_WAVE) + wave_in_block;
+    constexpr int RAYS_PER_TASK = RT_WAVE * RPL;
 
     const int n_lights = sc->n_lights;
     // the queue length is the same for every lane: keep it (and all loop bounds derived from it) scalar
     const unsigned int n_hits = __builtin_amdgcn_readfirstlane(*A.n_items);
     const unsigned long long n_rays = (MODE == 0) ? n_hits : (unsigned long long)n_hits * n_lights;
-    const unsigned int n_ray_blocks = (unsigned int)((n_rays + RT_WAVE - 1) / RT_WAVE);
-    const int NR = sc->n_regular;
+    const unsigned int n_ray_blocks = (unsigned int)((n_rays + RAYS_PER_TASK - 1) / RAYS_PER_TASK);
+    const int NR = sc->n_regular, NI = sc->n_irregular, NS = sc->n_spheres;
     // Split the triangle range over several waves when there are too few rays to fill the chip.
     int max_split = (NR + 2047) / 2048;
     if (max_split < 1) max_split = 1;
@@ -192,110 +201,167 @@ k_trace(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, c
         split = (2 * n_waves + n_ray_blocks - 1) / n_ray_blocks;
         if (split > max_split) split = max_split;
     }
-    const unsigned long long n_tasks = (unsigned long long)n_ray_blocks * split;
+    const unsigned int n_tasks = n_ray_blocks * (unsigned int)split;   // < 2^31: n_ray_blocks * split <= ~4 * n_waves or n_ray_blocks
     const float eps = (MODE == 0) ? sc->eps : sc->shadow_eps;
     const FilterParams fp = (MODE == 0) ? sc->fp_closest : sc->fp_shadow;
+    const float ob = sc->origin_bound, vb = sc->dir_len2_bound;
+    const int n_groups = (MODE == 0) ? sc->n_groups : 1;
     unsigned int exact_total = 0;
 
-    for (unsigned long long task = wave_id; task < n_tasks; task += n_waves) {
-        const unsigned int rb = (unsigned int)(task % n_ray_blocks);
-        const int part = (int)(task / n_ray_blocks);
-        const unsigned long long ray = (unsigned long long)rb * RT_WAVE + lane;
-        const bool valid = ray < n_rays;
-        LaneState<MODE> L;
-        L.best_d = RT_MISS_T; L.best_obj = -1; L.source = -1; L.done = !valid; L.n_exact = 0;
-        d3 wpos = mk3(0, 0, 0), wvec = mk3(0, 0, 1);
-        unsigned int hit_index = 0, light_index = 0;
-        if (valid) {
-            if (MODE == 0) {
-                wpos = mk3(A.rays.ox[ray], A.rays.oy[ray], A.rays.oz[ray]);
-                wvec = mk3(A.rays.dx[ray], A.rays.dy[ray], A.rays.dz[ray]);
-            } else {
-                hit_index = (unsigned int)(ray / n_lights);
-                light_index = (unsigned int)(ray % n_lights);
-                wpos = mk3(A.rays.ox[hit_index], A.rays.oy[hit_index], A.rays.oz[hit_index]);
-                const DevLight& lt = sc->lights[light_index];
-                // Light::lightRay (raytracer.cpp:108-119)
-                d3 lv = lt.is_point ? sub3(ld3(lt.pos), wpos) : neg3(ld3(lt.pos));
-                wvec = nrm3(lv);
-                L.source = A.source_obj[hit_index];
-            }
+    for (unsigned int task = wave_id; task < n_tasks; task += n_waves) {
+        // integer division goes through the vector ALU; its result is still wave-uniform
+        const int part = __builtin_amdgcn_readfirstlane((int)(task / n_ray_blocks));
+        const unsigned int rb = task - (unsigned int)part * n_ray_blocks;
+        const unsigned long long ray0 = (unsigned long long)rb * RAYS_PER_TASK + lane;   // slot r: ray0 + r * 64
+        float best_d[RPL];
+        int best_obj[RPL];
+        bool done[RPL], invalid[RPL];     // done: slot needs no more tests (no ray, or already occluded)
+#pragma unroll
+        for (int r = 0; r < RPL; r++) {
+            best_d[r] = RT_MISS_T; best_obj[r] = -1;
+            invalid[r] = ray0 + (unsigned long long)r * RT_WAVE >= n_rays;
+            done[r] = invalid[r];
         }
 
         // ---- spheres and irregular triangles: always in reference precision (first part only) ----
-        if (part == 0) {
-            for (int s = 0; s < sc->n_spheres; s++) {
-                const SphereRec& S = sc->spheres[s];
-                const double* X = sc->xforms + 48 * (size_t)S.xf;
-                d3 pos = wpos, vec = wvec;
-                int ident = 1;
-                if (MODE == 0 && !S.identity) {       // shadow rays are never transformed (raytracer.cpp:553)
-                    pos = xf_point(X + 16, wpos); vec = xf_dir(X + 16, wvec); ident = 0;
+        if (part == 0 && NS + NI > 0) {
+#pragma unroll
+            for (int r = 0; r < RPL; r++) {
+                if (done[r]) continue;
+                d3 wpos, wvec;
+                int source;
+                load_world_ray<MODE>(A, sc, ray0 + (unsigned long long)r * RT_WAVE, n_lights, &wpos, &wvec, &source);
+                bool occ = false;
+                for (int s = 0; s < NS; s++) {
+                    const SphereRec& S = sc->spheres[s];
+                    const double* X = sc->xforms + 48 * (size_t)S.xf;
+                    d3 pos = wpos, vec = wvec;
+                    const int ident = (MODE == 0) ? S.identity : 1;   // shadow rays are never transformed (raytracer.cpp:553)
+                    to_object_space(X, ident, &pos, &vec);
+                    float t = sph_intersect_exact(S, pos, vec, eps);
+                    fold_result<MODE>(t, S.obj, pos, vec, X, ident, source, &best_d[r], &best_obj[r], &occ);
+                    exact_total++;
                 }
-                if (!L.done) exact_sphere<MODE>(L, S, pos, vec, X, ident, eps);
+                for (int g = 0; g < n_groups; g++) {
+                    int ibeg = NR, iend = NR + NI, ident = 1;
+                    const double* X = sc->xforms;
+                    if (MODE == 0) {
+                        const Group& G = sc->groups[g];
+                        ibeg = G.ibeg; iend = G.iend; ident = G.identity;
+                        X = sc->xforms + 48 * (size_t)G.xf;
+                    }
+                    d3 pos = wpos, vec = wvec;
+                    to_object_space(X, ident, &pos, &vec);
+                    for (int i = ibeg; i < iend; i++) {
+                        float t = tri_intersect_exact(exact[i], pos, vec, eps);
+                        fold_result<MODE>(t, exact[i].obj, pos, vec, X, ident, source, &best_d[r], &best_obj[r], &occ);
+                        exact_total++;
+                    }
+                }
+                if (MODE == 1 && occ) done[r] = true;
             }
         }
 
-        // ---- triangles, group by group ----
-        const int n_groups = (MODE == 0) ? sc->n_groups : 1;
+        // ---- regular triangles, group by group ----
         for (int g = 0; g < n_groups; g++) {
-            int fbeg, fend, ibeg, iend, ident = 1;
+            int fbeg = 0, fend = NR, ident = 1;
             const double* X = sc->xforms;
             if (MODE == 0) {
+                // group records are the same for every lane: keep the bounds in scalar registers
                 const Group& G = sc->groups[g];
-                fbeg = G.fbeg; fend = G.fend; ibeg = G.ibeg; iend = G.iend; ident = G.identity;
-                X = sc->xforms + 48 * (size_t)G.xf;
-                if (ident) { L.pos = wpos; L.vec = wvec; }
-                else { L.pos = xf_point(X + 16, wpos); L.vec = xf_dir(X + 16, wvec); }   // transformRay, raytracer.cpp:251
-            } else {
-                fbeg = 0; fend = NR; ibeg = NR; iend = NR + sc->n_irregular;
-                L.pos = wpos; L.vec = wvec;
-            }
-            if (part == 0) {
-                for (int i = ibeg; i < iend; i++)
-                    if (!L.done) exact_tri<MODE>(L, exact[i], X, ident, eps);
+                fbeg = __builtin_amdgcn_readfirstlane(G.fbeg); fend = __builtin_amdgcn_readfirstlane(G.fend);
+                ident = __builtin_amdgcn_readfirstlane(G.identity);
+                X = sc->xforms + 48 * (size_t)__builtin_amdgcn_readfirstlane(G.xf);
             }
             // this wave's share of the group's regular triangles
             const int glen = fend - fbeg;
-            const int pbeg = fbeg + (int)(((long long)glen * part) / split);
-            const int pend = fbeg + (int)(((long long)glen * (part + 1)) / split);
+            const int per_part = __builtin_amdgcn_readfirstlane((glen + split - 1) / split);
+            const int pbeg = fbeg + part * per_part;
+            const int pend = min(fend, pbeg + per_part);
+            if (pbeg >= pend) continue;
 
-            const float px = (float)L.pos.x, py = (float)L.pos.y, pz = (float)L.pos.z;
-            const float vx = (float)L.vec.x, vy = (float)L.vec.y, vz = (float)L.vec.z;
-            // Outside the bounds the margins were derived for (or NaN): test everything exactly.
-            const float ob = sc->origin_bound;
-            bool trusted = fabsf(px) <= ob && fabsf(py) <= ob && fabsf(pz) <= ob &&
-                           (vx * vx + vy * vy + vz * vz) <= sc->dir_len2_bound;
-            const bool force = A.force_exact || !trusted;
+            // FP32 copies of the rays in this group's object space
+            float px[RPL], py[RPL], pz[RPL], vx[RPL], vy[RPL], vz[RPL];
+            bool force[RPL];              // test everything exactly for this slot
+#pragma unroll
+            for (int r = 0; r < RPL; r++) {
+                d3 pos = mk3(0, 0, 0), vec = mk3(0, 0, 1);
+                int source;
+                if (!invalid[r]) {
+                    load_world_ray<MODE>(A, sc, ray0 + (unsigned long long)r * RT_WAVE, n_lights, &pos, &vec, &source);
+                    to_object_space(X, ident, &pos, &vec);
+                }
+                px[r] = (float)pos.x; py[r] = (float)pos.y; pz[r] = (float)pos.z;
+                vx[r] = (float)vec.x; vy[r] = (float)vec.y; vz[r] = (float)vec.z;
+                // Outside the bounds the margins were derived for (or NaN): no filtering.
+                const bool trusted = fabsf(px[r]) <= ob && fabsf(py[r]) <= ob && fabsf(pz[r]) <= ob &&
+                                     (vx[r] * vx[r] + vy[r] * vy[r] + vz[r] * vz[r]) <= vb;
+                force[r] = A.force_exact || !trusted;
+            }
 
             for (int cbeg = pbeg; cbeg < pend; cbeg += RT_CHUNK) {
                 const int cend = min(cbeg + RT_CHUNK, pend);
                 int n_cand = 0;
                 for (int j0 = cbeg; j0 < cend; j0 += RT_BATCH) {
                     const int jn = min(j0 + RT_BATCH, cend);
-                    if (MODE == 1 && !__any(!L.done)) break;
+                    if (MODE == 1) {
+                        bool all_done = true;
+#pragma unroll
+                        for (int r = 0; r < RPL; r++) all_done = all_done && done[r];
+                        if (!__any(!all_done)) break;
+                    }
                     // The record of triangle j+1 is requested before triangle j is evaluated
                     // (the array carries one padding record, so j+1 is always readable).
                     v16f cur = filt[j0];
 #pragma unroll 2
                     for (int j = j0; j < jn; j++) {
                         const v16f nxt = filt[j + 1];
-                        const bool c = filter_keep(cur, px, py, pz, vx, vy, vz, fp) | force;
-                        if (c && !L.done) {
-                            my_cand[n_cand * RT_BLOCK] = (unsigned short)(j - cbeg);
-                            n_cand++;
+                        bool c[RPL];
+#pragma unroll
+                        for (int r = 0; r < RPL; r++)
+                            c[r] = (filter_keep(cur, px[r], py[r], pz[r], vx[r], vy[r], vz[r], fp) | force[r]) & !done[r];
+#pragma unroll
+                        for (int r = 0; r < RPL; r++) {
+                            if (c[r]) {
+                                // The entry is built from a SCALAR register here, inside the branch;
+                                // otherwise the compiler moves the whole triangle counter (and with it
+                                // the address of every record load) to the vector ALU.
+                                unsigned int entry;
+                                asm volatile("v_mov_b32 %0, %1" : "=v"(entry) : "s"((j - cbeg) | (r << 15)));
+                                my_cand[n_cand * RT_BLOCK] = (unsigned short)entry;
+                                n_cand++;
+                            }
                         }
                         cur = nxt;
                     }
                     // Drain when some lane could overflow during the next batch, and at the end of the chunk.
                     const bool last = jn >= cend;
-                    if (__any(n_cand > RT_CAND_CAP - RT_BATCH) || (last && __any(n_cand > 0))) {
+                    if (__any(n_cand > RT_CAND_CAP - RT_BATCH * RPL) || (last && __any(n_cand > 0))) {
+                        unsigned int dmask = 0;
+#pragma unroll
+                        for (int r = 0; r < RPL; r++) dmask |= done[r] ? (1u << r) : 0u;
                         for (int k = 0; __any(k < n_cand); k++) {
-                            if (k < n_cand && !L.done) {
-                                const int j = cbeg + my_cand[k * RT_BLOCK];
-                                exact_tri<MODE>(L, exact[j], X, ident, eps);
-                            }
+                            if (k >= n_cand) continue;
+                            const unsigned int e = my_cand[k * RT_BLOCK];
+                            const int r = (int)(e >> 15);
+                            if ((dmask >> r) & 1u) continue;
+                            const int j = cbeg + (int)(e & 0x7fffu);
+                            // the ray in reference precision, re-read and re-transformed on demand
+                            d3 pos, vec;
+                            int source;
+                            load_world_ray<MODE>(A, sc, ray0 + (unsigned long long)r * RT_WAVE, n_lights, &pos, &vec, &source);
+                            to_object_space(X, ident, &pos, &vec);
+                            const TriExact& T = exact[j];
+                            const float t = tri_intersect_exact(T, pos, vec, eps);
+                            exact_total++;
+                            bool occ = false;
+#pragma unroll
+                            for (int rr = 0; rr < RPL; rr++)
+                                if (rr == r) fold_result<MODE>(t, T.obj, pos, vec, X, ident, source, &best_d[rr], &best_obj[rr], &occ);
+                            if (MODE == 1 && occ) dmask |= 1u << r;
                         }
+#pragma unroll
+                        for (int r = 0; r < RPL; r++) done[r] = (dmask >> r) & 1u;
                         n_cand = 0;
                     }
                 }
@@ -303,14 +369,17 @@ k_trace(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, c
         }
 
         // ---- publish ----
-        if (valid) {
+#pragma unroll
+        for (int r = 0; r < RPL; r++) {
+            if (invalid[r]) continue;
+            const unsigned long long ray = ray0 + (unsigned long long)r * RT_WAVE;
             if (MODE == 0) {
-                if (L.best_obj >= 0) atomicMin(&A.keys[ray], make_key(L.best_d, L.best_obj));
-            } else if (L.done) {
-                atomicOr(&A.occluded[(size_t)hit_index * A.occl_words + (light_index >> 5)], 1u << (light_index & 31));
+                if (best_obj[r] >= 0) atomicMin(&A.keys[ray], make_key(best_d[r], best_obj[r]));
+            } else if (done[r]) {
+                const unsigned int hit = (unsigned int)(ray / n_lights), light = (unsigned int)(ray % n_lights);
+                atomicOr(&A.occluded[(size_t)hit * A.occl_words + (light >> 5)], 1u << (light & 31));
             }
         }
-        exact_total += L.n_exact;
     }
     // one counter update per wave
     for (int off = 32; off > 0; off >>= 1) exact_total += __shfl_xor(exact_total, off);
