@@ -23,10 +23,14 @@
 
 #define RT_BLOCK 256
 #define RT_WAVE 64
-#define RT_CAND_CAP 48          // per-lane candidate slots in LDS (shared by the lane's rays)
-#define RT_BATCH 16             // triangles filtered between two capacity checks
-#define RT_CHUNK 32768          // candidate = 15-bit triangle index relative to a chunk base + ray slot in bit 15
-#define RT_RPL 2                // rays per lane in the trace kernels
+#define RT_CAND_CAP 64          // per-lane candidate slots in LDS (shared by the lane's rays)
+#define RT_BATCH 8              // triangles filtered between two capacity checks
+#ifndef RT_TRACE_MIN_WAVES
+#define RT_TRACE_MIN_WAVES 1     // minimum waves per SIMD the trace kernels are compiled for
+#endif
+#define RT_RPL 4                // rays per lane in the trace kernels
+#define RT_SLOT_SHIFT 14        // candidate entry (u16) = triangle index relative to a chunk base | ray slot << 14
+#define RT_CHUNK (1 << RT_SLOT_SHIFT)
 
 struct RayQueue {               // structure of arrays, one entry per ray
     double *ox, *oy, *oz, *dx, *dy, *dz;
@@ -171,7 +175,7 @@ __device__ __forceinline__ bool filter_keep(const v16f f, float px, float py, fl
 }
 
 template <int MODE, int RPL>
-__global__ void __launch_bounds__(RT_BLOCK)
+__global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_MIN_WAVES)
 k_trace(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, const TriExact* __restrict__ exact,
         TraceArgs A) {
     // The filter records are never written while a kernel runs: reading them through the
@@ -316,20 +320,25 @@ k_trace(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, c
 #pragma unroll 2
                     for (int j = j0; j < jn; j++) {
                         const v16f nxt = filt[j + 1];
-                        bool c[RPL];
-#pragma unroll
-                        for (int r = 0; r < RPL; r++)
-                            c[r] = (filter_keep(cur, px[r], py[r], pz[r], vx[r], vy[r], vz[r], fp) | force[r]) & !done[r];
+                        bool c[RPL], any = false;
 #pragma unroll
                         for (int r = 0; r < RPL; r++) {
-                            if (c[r]) {
-                                // The entry is built from a SCALAR register here, inside the branch;
-                                // otherwise the compiler moves the whole triangle counter (and with it
-                                // the address of every record load) to the vector ALU.
-                                unsigned int entry;
-                                asm volatile("v_mov_b32 %0, %1" : "=v"(entry) : "s"((j - cbeg) | (r << 15)));
-                                my_cand[n_cand * RT_BLOCK] = (unsigned short)entry;
-                                n_cand++;
+                            c[r] = (filter_keep(cur, px[r], py[r], pz[r], vx[r], vy[r], vz[r], fp) | force[r]) & !done[r];
+                            any |= c[r];
+                        }
+                        // one (rarely taken) region per triangle for all of the lane's rays
+                        if (any) {
+                            // The entry is built from a SCALAR register here, inside the branch;
+                            // otherwise the compiler moves the whole triangle counter (and with it
+                            // the address of every record load) to the vector ALU.
+                            unsigned int entry;
+                            asm volatile("v_mov_b32 %0, %1" : "=v"(entry) : "s"(j - cbeg));
+#pragma unroll
+                            for (int r = 0; r < RPL; r++) {
+                                if (c[r]) {
+                                    my_cand[n_cand * RT_BLOCK] = (unsigned short)(entry | (r << RT_SLOT_SHIFT));
+                                    n_cand++;
+                                }
                             }
                         }
                         cur = nxt;
@@ -343,9 +352,9 @@ k_trace(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, c
                         for (int k = 0; __any(k < n_cand); k++) {
                             if (k >= n_cand) continue;
                             const unsigned int e = my_cand[k * RT_BLOCK];
-                            const int r = (int)(e >> 15);
+                            const int r = (int)(e >> RT_SLOT_SHIFT);
                             if ((dmask >> r) & 1u) continue;
-                            const int j = cbeg + (int)(e & 0x7fffu);
+                            const int j = cbeg + (int)(e & ((1u << RT_SLOT_SHIFT) - 1u));
                             // the ray in reference precision, re-read and re-transformed on demand
                             d3 pos, vec;
                             int source;
