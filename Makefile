@@ -15,12 +15,12 @@ host: $(PKG)/librt_host.so
 hip: $(PKG)/libraytracer_amd.so
 
 $(PKG)/librt_host.so: $(HOST_SRC) include/rt_host.h include/rt_abi.h
-	$(CXX) -O2 -std=c++17 -ffp-contract=off -fPIC -shared -Iinclude -o $@ $(HOST_SRC) -lz
+	$(CXX) -O2 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -Iinclude -o $@ $(HOST_SRC) -lz
 
 # -ffp-contract=off: the reference-precision device code must not fuse a*b+c;
 # the FP32 filter asks for its FMAs explicitly.
 $(PKG)/libraytracer_amd.so: $(HIP_SRC) $(HIP_HDR)
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Iinclude -I$(PKG)/csrc \
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -Iinclude -I$(PKG)/csrc \
 	  -o $@ $(HIP_SRC)
 
 oracle:

@@ -7,7 +7,8 @@ every rank traces its interleaved 16-row scanline tiles through the C ABI
 (rt_render_tiles) and the tiles are gathered to rank 0.  Inputs (the uploaded scene) are
 resident in HBM before the timed region.  Rank 0 prints one JSON line.
 
-  roofline      the dominant kernel (nearest-hit or shadow scan, whichever took longer):
+  roofline      the dominant kernel (the FP32 filter scan k_filter, nearest-hit or shadow
+                instance, whichever took longer):
                 algorithmic FLOP = ray x primitive pairs scanned x 42 (triangle) or 28
                 (sphere), divided by the kernel's summed duration measured with HIP events
                 on the launch stream, against the 157.3 TFLOP/s FP32 vector peak.
@@ -134,8 +135,8 @@ def main():
     if rank == 0:
         n_tri, n_sph = st["n_triangles"], st["n_spheres"]
         flop_per_test = (FLOP_TRI * n_tri + FLOP_SPH * n_sph) / max(1, n_tri + n_sph)
-        kernels = {"k_trace<0> (nearest hit)": (st["closest_ms"], st["closest_tests"], st["closest_launches"]),
-                   "k_trace<1> (shadow)": (st["anyhit_ms"], st["anyhit_tests"], st["anyhit_launches"])}
+        kernels = {"k_filter<0> (nearest hit)": (st["closest_ms"], st["closest_tests"], st["closest_launches"]),
+                   "k_filter<1> (shadow)": (st["anyhit_ms"], st["anyhit_tests"], st["anyhit_launches"])}
         dom = max(kernels, key=lambda k: kernels[k][0])
         ms, tests, launches = kernels[dom]
         achieved = tests * flop_per_test / (ms * 1e-3) if ms > 0 else 0.0
@@ -163,7 +164,9 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU, "traffic": None,
                          "kernel_ms_avg": ms / max(1, launches), "launches": launches,
                          "flop_per_test": flop_per_test, "tests_per_launch": tests / max(1, launches),
-                         "both_trace_kernels_tflops": both / 1e12,
+                         "both_filter_kernels_tflops": both / 1e12,
+                         "filter_ms_per_step": both_ms / args.steps,
+                         "reference_precision_kernels_ms_per_step": st["exact_ms"] / args.steps,
                          "exact_retests_per_ray": st["exact_tests"] / max(1, rays_local)},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -98,13 +98,15 @@ typedef struct rt_stats {
     uint64_t rays_reflect;   /* recursive traceRay calls (raytracer.cpp:543) */
     uint64_t rays_shadow;    /* traceShadowRay calls (raytracer.cpp:567) */
     uint64_t hits;           /* traceRay calls that found an object */
-    uint64_t closest_tests;  /* ray x primitive pairs scanned by the nearest-hit kernel */
-    uint64_t anyhit_tests;   /* ray x primitive pairs scanned by the shadow kernel (nominal: no early out) */
-    uint64_t exact_tests;    /* candidate pairs re-evaluated in reference precision */
-    double closest_ms;       /* RT_OPT_PROFILE: summed duration of nearest-hit kernel launches */
-    double anyhit_ms;        /* RT_OPT_PROFILE: summed duration of shadow kernel launches */
-    uint32_t closest_launches, anyhit_launches;
+    uint64_t closest_tests;  /* ray x primitive pairs scanned for nearest hits */
+    uint64_t anyhit_tests;   /* ray x primitive pairs scanned for shadow rays */
+    uint64_t exact_tests;    /* pairs evaluated in reference precision */
+    double closest_ms;       /* RT_OPT_PROFILE: summed duration of the nearest-hit filter kernel launches */
+    double anyhit_ms;        /* RT_OPT_PROFILE: summed duration of the shadow filter kernel launches */
+    double exact_ms;         /* RT_OPT_PROFILE: summed duration of the reference-precision kernels */
+    uint32_t closest_launches, anyhit_launches, exact_launches;
     int32_t n_triangles, n_spheres, n_groups, n_irregular;
+    int32_t reserved;
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;

@@ -107,21 +107,25 @@ struct rt_ctx {
     DevBuf<int32_t> lvl_parent, lvl_obj;   // [levels][cap]
     DevBuf<double> lvl_phong, lvl_child;   // [levels][3][cap]
     DevBuf<uint32_t> counts;       // [levels + 1]
+    DevBuf<uint8_t> ray_flags;     // [cap * max(1, n_lights)]
+    DevBuf<unsigned long long> pairs;
+    DevBuf<unsigned int> pair_count;
+    size_t pair_cap = 0;
 
     // options
     int force_exact = 0;
     int profile = 0;
     long long pass_pixels = 4 << 20;
 
-    int trace_grid[2] = {0, 0};
+    int filter_grid[2] = {0, 0};
     int aux_grid = 0;
     hipStream_t last_stream = nullptr;
 
     struct Span { hipEvent_t a, b; int kind; };
     std::vector<Span> spans;
     std::vector<hipEvent_t> event_pool;
-    double ms[2] = {0, 0};
-    unsigned launches[2] = {0, 0};
+    double ms[3] = {0, 0, 0};      // filter MODE 0, filter MODE 1, reference-precision kernels
+    unsigned launches[3] = {0, 0, 0};
 };
 
 namespace {
@@ -163,6 +167,13 @@ int ensure_workspace(rt_ctx* c) {
     HIP_TRY(c->lvl_phong.alloc((size_t)levels * 3 * want));
     HIP_TRY(c->lvl_child.alloc((size_t)levels * 3 * want));
     HIP_TRY(c->counts.alloc(levels + 2));
+    const size_t shadow_rays = want * (size_t)std::max(1, c->hs.n_lights);
+    if (shadow_rays >= (1ull << 31)) return fail(RT_ERR_RANGE, "pass too large: lower RT_OPT_PASS_PIXELS");
+    HIP_TRY(c->ray_flags.alloc(shadow_rays));
+    // room for 16 listed pairs per ray of the largest launch (a few are typical), 8 B each
+    c->pair_cap = std::min<size_t>(std::max<size_t>(shadow_rays * 16, 1u << 20), 1u << 28);
+    HIP_TRY(c->pairs.alloc(c->pair_cap));
+    HIP_TRY(c->pair_count.alloc(1));
     return 0;
 }
 
@@ -191,20 +202,46 @@ void drain_spans(rt_ctx* c) {
     c->spans.clear();
 }
 
+struct Timed {
+    rt_ctx* c; hipStream_t st; int kind; hipEvent_t a = nullptr, b = nullptr;
+    Timed(rt_ctx* c_, hipStream_t st_, int kind_) : c(c_), st(st_), kind(kind_) {
+        if (c->profile) {
+            a = take_event(c); b = take_event(c);
+            if (a && b) (void)hipEventRecord(a, st);
+        }
+    }
+    void stop() {
+        if (a && b) {
+            (void)hipEventRecord(b, st);
+            c->spans.push_back({a, b, kind});
+        }
+    }
+};
+
+// Nearest hit (MODE 0) or shadow (MODE 1) of one queue: filter, listed pairs, the rest.
 template <int MODE>
-int launch_trace(rt_ctx* c, const TraceArgs& A, hipStream_t st) {
-    hipEvent_t ea = nullptr, eb = nullptr;
-    if (c->profile) {
-        ea = take_event(c); eb = take_event(c);
-        if (ea && eb) HIP_TRY(hipEventRecord(ea, st));
+int launch_trace(rt_ctx* c, TraceArgs A, hipStream_t st) {
+    const DevScene* dsc = c->d_scene.p;
+    A.ray_flags = c->ray_flags.p; A.pairs = c->pairs.p; A.pair_count = c->pair_count.p;
+    A.pair_cap = (unsigned int)c->pair_cap; A.counters = c->counters.p; A.scan_all = c->force_exact;
+    HIP_TRY(hipMemsetAsync(c->pair_count.p, 0, sizeof(unsigned int), st));
+    HIP_TRY(hipMemsetAsync(c->ray_flags.p, 0, c->ray_flags.n, st));
+    if (!c->force_exact && c->hs.n_regular > 0) {
+        Timed t(c, st, MODE);
+        hipLaunchKernelGGL((k_filter<MODE, RT_RPL>), dim3(c->filter_grid[MODE]), dim3(RT_BLOCK), 0, st, dsc,
+                           (const v16f*)c->tri_filt.p, A);
+        HIP_TRY(hipGetLastError());
+        t.stop();
     }
-    hipLaunchKernelGGL((k_trace<MODE, RT_RPL>), dim3(c->trace_grid[MODE]), dim3(RT_BLOCK), 0, st,
-                       (const DevScene*)c->d_scene.p, (const v16f*)c->tri_filt.p, (const TriExact*)c->tri_exact.p, A);
+    Timed t(c, st, 2);
+    if (!c->force_exact && c->hs.n_regular > 0) {
+        hipLaunchKernelGGL(k_exact_pairs<MODE>, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, dsc,
+                           (const TriExact*)c->tri_exact.p, A);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_brute<MODE>, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, dsc, (const TriExact*)c->tri_exact.p, A);
     HIP_TRY(hipGetLastError());
-    if (ea && eb) {
-        HIP_TRY(hipEventRecord(eb, st));
-        c->spans.push_back({ea, eb, MODE});
-    }
+    t.stop();
     return 0;
 }
 
@@ -227,7 +264,7 @@ int run_pass(rt_ctx* c, PassDesc pd, int nrows, hipStream_t st) {
         LevelStore lvl = level_of(c, k);
         TraceArgs ta{};
         ta.rays = q[cur]; ta.n_items = c->counts.p + k; ta.keys = c->keys[cur].p;
-        ta.force_exact = c->force_exact; ta.counters = c->counters.p; ta.occl_words = c->occl_words;
+        ta.occl_words = c->occl_words;
         int rc = launch_trace<0>(c, ta, st);
         if (rc) return rc;
 
@@ -242,7 +279,6 @@ int run_pass(rt_ctx* c, PassDesc pd, int nrows, hipStream_t st) {
             TraceArgs sa{};
             sa.rays = q[nxt]; sa.n_items = c->counts.p + k + 1; sa.source_obj = lvl.obj;
             sa.occluded = c->occluded.p; sa.occl_words = c->occl_words;
-            sa.force_exact = c->force_exact; sa.counters = c->counters.p;
             rc = launch_trace<1>(c, sa, st);
             if (rc) return rc;
         }
@@ -412,10 +448,10 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
     };
     const FilterParams fpc = thresholds(d->eps), fps = thresholds(d->shadow_eps);
     const double b_lo_min = std::max(1e-30, (double)std::min(fpc.b_lo, fps.b_lo));
-    const double amp = 18.0 * vmax / b_lo_min + 17.0;          // position-error amplification of a grazing ray
+    const double amp = 18.0 * vmax / b_lo_min + 20.0;          // position-error amplification of a grazing ray
 
     // ---- triangles: reference-precision records, filter planes, regular / irregular split ----
-    struct TriTmp { TriExact ex; float4 f[4]; bool regular; int xf; };
+    struct TriTmp { TriExact ex; float f[16]; bool regular; int xf; int axis; };
     std::vector<TriTmp> tris;
     std::vector<SphereRec> sph;
     std::vector<int32_t> slot(N, -1);
@@ -460,22 +496,40 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
             // rounding of the reference's own float formula
             double dBs = 2 * EPSF * wmax * (std::fabs(fuv) * le2 + fvv * le1) / std::fabs(fD) + 3 * EPSF;
             double dBt = 2 * EPSF * wmax * (std::fabs(fuv) * le1 + fuu * le2) / std::fabs(fD) + 3 * EPSF;
-            // rounding of the FP32 filter itself (hit position and plane evaluation)
-            double dAs = EPSF * vlen(S) * R * amp, dAt = EPSF * vlen(T) * R * amp;
-            double ds = 4 * (dAs + dBs) + 1e-6, dt = 4 * (dAt + dBt) + 1e-6, du = ds + dt;
-            ok = std::isfinite(ds) && std::isfinite(dt) && dBs < 0.125 && dBt < 0.125 && du < 1e6;
+            ok = dBs < 0.125 && dBt < 0.125 && std::isfinite(dBs) && std::isfinite(dBt);
             if (ok) {
+                // Each coordinate as a function of the two hit-point coordinates (u, v) other than
+                // the normal's dominant axis k: on the plane x_k = (d0 - n_u x_u - n_v x_v) / n_k.
                 double d0 = vdot(n, v1);
-                double os = -vdot(S, v1) + ds, ot = -vdot(T, v1) + dt;
+                double nn[3] = {n.x, n.y, n.z};
+                int k = 0;
+                if (std::fabs(nn[1]) > std::fabs(nn[k])) k = 1;
+                if (std::fabs(nn[2]) > std::fabs(nn[k])) k = 2;
+                const int iu = (k + 1) % 3, iv = (k + 2) % 3;
+                t.axis = k;
                 Vec U{-(S.x + T.x), -(S.y + T.y), -(S.z + T.z)};
-                double ou = 1.0 - vdot(U, v1) + du;
-                t.f[0] = make_float4((float)n.x, (float)n.y, (float)n.z, (float)d0);
-                t.f[1] = make_float4((float)S.x, (float)S.y, (float)S.z, (float)os);
-                t.f[2] = make_float4((float)T.x, (float)T.y, (float)T.z, (float)ot);
-                t.f[3] = make_float4((float)U.x, (float)U.y, (float)U.z, (float)ou);
-                for (int k = 0; k < 4; k++)
-                    ok = ok && std::isfinite(t.f[k].x) && std::isfinite(t.f[k].y) && std::isfinite(t.f[k].z) &&
-                         std::isfinite(t.f[k].w);
+                const double off3[3] = {-vdot(S, v1), -vdot(T, v1), 1.0 - vdot(U, v1)};
+                const Vec* planes[3] = {&S, &T, &U};
+                double coef[3][3];
+                double norm2d[3];
+                for (int q = 0; q < 3; q++) {
+                    double pc[3] = {planes[q]->x, planes[q]->y, planes[q]->z};
+                    coef[q][0] = pc[iu] - pc[k] * nn[iu] / nn[k];
+                    coef[q][1] = pc[iv] - pc[k] * nn[iv] / nn[k];
+                    coef[q][2] = off3[q] + pc[k] * d0 / nn[k];
+                    norm2d[q] = std::sqrt(coef[q][0] * coef[q][0] + coef[q][1] * coef[q][1]);
+                }
+                // rounding of the FP32 filter itself (hit position and plane evaluation)
+                double dAs = EPSF * norm2d[0] * R * amp, dAt = EPSF * norm2d[1] * R * amp;
+                double ds = 4 * (dAs + dBs) + 1e-6, dt = 4 * (dAt + dBt) + 1e-6, du = ds + dt;
+                ok = std::isfinite(ds) && std::isfinite(dt) && du < 1e6;
+                float* f = t.f;
+                f[0] = (float)n.x; f[1] = (float)n.y; f[2] = (float)n.z; f[3] = (float)d0;
+                f[4] = (float)coef[0][0]; f[5] = (float)coef[0][1]; f[6] = (float)(coef[0][2] + ds);
+                f[7] = (float)coef[1][0]; f[8] = (float)coef[1][1]; f[9] = (float)(coef[1][2] + dt);
+                f[10] = (float)coef[2][0]; f[11] = (float)coef[2][1]; f[12] = (float)(coef[2][2] + du);
+                f[13] = f[14] = f[15] = 0.f;
+                for (int q = 0; q < 13; q++) ok = ok && std::isfinite(f[q]);
             }
         }
         t.regular = ok;
@@ -486,7 +540,10 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
     std::vector<int> order_reg, order_irr;
     for (int k = 0; k < (int)tris.size(); k++) (tris[k].regular ? order_reg : order_irr).push_back(k);
     auto by_xf = [&](int a, int b) { return tris[a].xf < tris[b].xf; };
-    std::stable_sort(order_reg.begin(), order_reg.end(), by_xf);
+    auto by_xf_axis = [&](int a, int b) {
+        return tris[a].xf != tris[b].xf ? tris[a].xf < tris[b].xf : tris[a].axis < tris[b].axis;
+    };
+    std::stable_sort(order_reg.begin(), order_reg.end(), by_xf_axis);
     std::stable_sort(order_irr.begin(), order_irr.end(), by_xf);
     const int NR = (int)order_reg.size(), NI = (int)order_irr.size();
     std::vector<v16f> filt((size_t)NR + 1);          // + one readable padding record
@@ -494,10 +551,7 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
     std::vector<TriExact> exact((size_t)NR + NI);
     for (int k = 0; k < NR; k++) {
         const TriTmp& t = tris[order_reg[k]];
-        for (int j = 0; j < 4; j++) {
-            filt[k][4 * j] = t.f[j].x; filt[k][4 * j + 1] = t.f[j].y;
-            filt[k][4 * j + 2] = t.f[j].z; filt[k][4 * j + 3] = t.f[j].w;
-        }
+        for (int j = 0; j < 16; j++) filt[k][j] = t.f[j];
         exact[k] = t.ex;
         slot[t.ex.obj] = k;
     }
@@ -515,12 +569,16 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
             int x = std::min(xr, xq);
             Group G{};
             G.xf = x; G.identity = xf_ident[x];
-            G.fbeg = r;
-            while (r < NR && tris[order_reg[r]].xf == x) r++;
-            G.fend = r;
+            for (int a = 0; a < 3; a++) {
+                G.fax[a] = r;
+                while (r < NR && tris[order_reg[r]].xf == x && tris[order_reg[r]].axis == a) r++;
+            }
+            G.fax[3] = r;
             G.ibeg = NR + q;
             while (q < NI && tris[order_irr[q]].xf == x) q++;
             G.iend = NR + q;
+            for (int k2 = G.fax[0]; k2 < G.fax[3]; k2++) exact[k2].grp = (int32_t)groups.size();
+            for (int k2 = G.ibeg; k2 < G.iend; k2++) exact[k2].grp = (int32_t)groups.size();
             groups.push_back(G);
         }
     }
@@ -578,14 +636,14 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
     if (e == hipSuccess) e = hipMemset(c->counters.p, 0, sizeof(DevCounters));
     if (e != hipSuccess) return bail(fail(RT_ERR_DEVICE, std::string("init: ") + hipGetErrorString(e)));
 
-    // launch geometry: as many resident blocks as the trace kernels admit
+    // launch geometry: as many resident blocks as the filter kernels admit
     for (int m = 0; m < 2; m++) {
         int nb = 0;
         hipError_t oe = (m == 0)
-            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<0, RT_RPL>, RT_BLOCK, 0)
-            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<1, RT_RPL>, RT_BLOCK, 0);
+            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_filter<0, RT_RPL>, RT_BLOCK, 0)
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_filter<1, RT_RPL>, RT_BLOCK, 0);
         if (oe != hipSuccess || nb < 1) nb = 2;
-        c->trace_grid[m] = c->n_cu * std::min(nb, 8);
+        c->filter_grid[m] = c->n_cu * std::min(nb, 8);
     }
     c->aux_grid = c->n_cu * 8;
     *out = c;
@@ -655,6 +713,7 @@ int rt_get_stats(rt_ctx* c, rt_stats* out) {
     out->exact_tests = dc.exact_tests;
     out->closest_ms = c->ms[0]; out->anyhit_ms = c->ms[1];
     out->closest_launches = c->launches[0]; out->anyhit_launches = c->launches[1];
+    out->exact_ms = c->ms[2]; out->exact_launches = c->launches[2];
     out->n_triangles = c->hs.n_regular + c->hs.n_irregular; out->n_spheres = c->hs.n_spheres;
     out->n_groups = c->hs.n_groups; out->n_irregular = c->hs.n_irregular;
     return 0;
@@ -665,7 +724,7 @@ int rt_reset_stats(rt_ctx* c) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->last_stream));
     drain_spans(c);
-    c->ms[0] = c->ms[1] = 0; c->launches[0] = c->launches[1] = 0;
+    for (int k = 0; k < 3; k++) { c->ms[k] = 0; c->launches[k] = 0; }
     HIP_TRY(hipMemset(c->counters.p, 0, sizeof(DevCounters)));
     return 0;
 }
@@ -684,6 +743,7 @@ void rt_free(rt_ctx* c) {
     for (int i = 0; i < 2; i++) { c->rayq[i].release(); c->keys[i].release(); }
     c->aux.release(); c->occluded.release(); c->pixel_of_ray.release(); c->lvl_parent.release();
     c->lvl_obj.release(); c->lvl_phong.release(); c->lvl_child.release(); c->counts.release();
+    c->ray_flags.release(); c->pairs.release(); c->pair_count.release();
     delete c;
 }
 

@@ -15,10 +15,7 @@ struct d3 { double x, y, z; };
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(4))) const v16f cv16f;
 
-// Regular triangle, FP32 filter form: four float4 per triangle
-//   [0] unit normal n, plane offset d0 = n.v1
-//   [1..3] the barycentric coordinates s, t and u = 1-s-t as affine functions of a
-//          point, each with its safety margin folded into the offset.
+// Regular triangle, FP32 filter form: 16 floats (layout at filter_keep in rt_kernels.h).
 // Reference-precision form of the same triangle (128 bytes):
 struct __attribute__((aligned(16))) TriExact {
     double v1[3];      // vertex1
@@ -27,7 +24,8 @@ struct __attribute__((aligned(16))) TriExact {
     double n[3];       // (edge2 ^ edge1).normalize() (raytracer.cpp:313)
     float uu, uv, vv, D;   // raytracer.cpp:334-340, each rounded as the reference does
     int32_t obj;       // index in Scene::objects
-    int32_t pad[3];
+    int32_t grp;       // index of the transform group
+    int32_t pad[2];
 };
 
 struct __attribute__((aligned(16))) SphereRec {
@@ -36,15 +34,14 @@ struct __attribute__((aligned(16))) SphereRec {
     int32_t obj, xf, identity, pad;
 };
 
-// Triangles that share one transform.  Filter slots [fbeg, fend) are regular
+// Triangles that share one transform.  Filter slots [fax[0], fax[3]) are regular
 // triangles; exact slots [ibeg, iend) hold the group's irregular triangles
 // (degenerate, non-finite, or too ill-conditioned for the FP32 filter), which
 // are always tested in reference precision.
 struct Group {
     int32_t xf, identity;
-    int32_t fbeg, fend;
+    int32_t fax[4];    // filter slots [fax[k], fax[k+1]): triangles whose normal's dominant axis is k
     int32_t ibeg, iend;
-    int32_t pad[2];
 };
 
 struct DevMaterial { double ka[3], kd[3], ks[3], kr[3]; double sp; };

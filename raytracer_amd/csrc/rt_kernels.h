@@ -23,14 +23,11 @@
 
 #define RT_BLOCK 256
 #define RT_WAVE 64
-#define RT_CAND_CAP 64          // per-lane candidate slots in LDS (shared by the lane's rays)
-#define RT_BATCH 8              // triangles filtered between two capacity checks
-#ifndef RT_TRACE_MIN_WAVES
-#define RT_TRACE_MIN_WAVES 1     // minimum waves per SIMD the trace kernels are compiled for
-#endif
-#define RT_RPL 4                // rays per lane in the trace kernels
-#define RT_SLOT_SHIFT 14        // candidate entry (u16) = triangle index relative to a chunk base | ray slot << 14
-#define RT_CHUNK (1 << RT_SLOT_SHIFT)
+#define RT_CAND_CAP 64          // per-lane candidate staging slots in LDS (shared by the lane's rays)
+#define RT_BATCH 4              // triangles filtered between two capacity checks
+#define RT_RPL 8                // rays per lane in the filter kernel
+// a staged candidate (u16) = triangle index relative to a chunk base | ray slot << shift
+#define RT_SLOT_SHIFT(RPL) ((RPL) <= 2 ? 15 : ((RPL) <= 4 ? 14 : 13))
 
 struct RayQueue {               // structure of arrays, one entry per ray
     double *ox, *oy, *oz, *dx, *dy, *dz;
@@ -88,7 +85,19 @@ k_primary(const DevScene* __restrict__ sc, PassDesc pd, int n_pix, RayQueue q,
 }
 
 // ---------------------------------------------------------------------------
-// Brute-force scan.  MODE 0: nearest hit; MODE 1: any hit (shadow).
+// Brute-force scan of every primitive for every ray.
+// MODE 0: nearest hit (Scene::traceRay's object loop, raytracer.cpp:519-530).
+// MODE 1: any hit (Scene::traceShadowRay, raytracer.cpp:551-558).
+//
+//   k_filter       FP32 test of every (ray, regular triangle) pair; pairs that cannot be
+//                  ruled out go to a pair list in HBM (staged per lane in LDS).  This is the
+//                  kernel that does the O(rays x triangles) work.
+//   k_exact_pairs  the listed pairs again, in the reference's mixed double/float arithmetic;
+//                  results are merged per ray with atomicMin / atomicOr.
+//   k_brute        everything that never goes through the filter, in reference arithmetic:
+//                  spheres, irregular triangles, and ALL triangles for rays flagged by
+//                  k_filter (origin outside the bounds the filter margins were derived for,
+//                  NaN, pair list full) or when the filter is switched off.
 // ---------------------------------------------------------------------------
 struct TraceArgs {
     RayQueue rays;                       // MODE 0: the level's rays.  MODE 1: origins = hit points
@@ -97,7 +106,11 @@ struct TraceArgs {
     const int32_t* source_obj;           // MODE 1: object each hit lies on (excluded, raytracer.cpp:553)
     uint32_t* occluded;                  // MODE 1: per hit, one bit per light
     int32_t occl_words;                  // MODE 1: 32-bit words per hit
-    int32_t force_exact;                 // 1: bypass the FP32 filter
+    int32_t scan_all;                    // k_brute: 1 = test every triangle for every ray (filter switched off)
+    uint8_t* ray_flags;                  // per ray: 1 = k_brute must scan every triangle for it
+    unsigned long long* pairs;           // (ray << 32) | exact-record slot
+    unsigned int* pair_count;            // pairs appended so far (may run past pair_cap: the surplus is dropped)
+    unsigned int pair_cap;
     DevCounters* counters;
 };
 
@@ -106,13 +119,13 @@ struct TraceArgs {
 // raytracer.cpp:108-119); *source = the object the hit lies on.
 template <int MODE>
 __device__ __forceinline__ void load_world_ray(const TraceArgs& A, const DevScene* __restrict__ sc,
-                                               unsigned long long ray, int n_lights, d3* pos, d3* vec, int* source) {
+                                               unsigned int ray, unsigned int n_lights, d3* pos, d3* vec, int* source) {
     if (MODE == 0) {
         *pos = mk3(A.rays.ox[ray], A.rays.oy[ray], A.rays.oz[ray]);
         *vec = mk3(A.rays.dx[ray], A.rays.dy[ray], A.rays.dz[ray]);
         *source = -1;
     } else {
-        const unsigned int hit = (unsigned int)(ray / n_lights), light = (unsigned int)(ray % n_lights);
+        const unsigned int hit = ray / n_lights, light = ray - hit * n_lights;
         *pos = mk3(A.rays.ox[hit], A.rays.oy[hit], A.rays.oz[hit]);
         const DevLight& lt = sc->lights[light];
         d3 lv = lt.is_point ? sub3(ld3(lt.pos), *pos) : neg3(ld3(lt.pos));
@@ -129,30 +142,39 @@ __device__ __forceinline__ void to_object_space(const double* X, int identity, d
     }
 }
 
-// One primitive tested in reference precision; folds the result into the ray's running
-// answer.  MODE 0: (metric, object) with the reference's strict '<' and lowest-index tie
-// rule (raytracer.cpp:525).  MODE 1: any hit other than the source (raytracer.cpp:553;
-// a NaN result counts as a hit there because NaN != MAXFLOAT).
+// Merges one reference-precision test result into the ray's global answer.
+// MODE 0: (metric, object) with the reference's strict '<' against MAXFLOAT and its
+// lowest-index tie rule (raytracer.cpp:516, 525) -- the 64-bit key orders exactly that way.
+// MODE 1: any hit other than the source (raytracer.cpp:553; a NaN result counts as a hit
+// there because NaN != MAXFLOAT).
 template <int MODE>
-__device__ __forceinline__ void fold_result(float t, int obj, d3 pos, d3 vec, const double* X, int identity,
-                                            int source, float* best_d, int* best_obj, bool* occluded) {
+__device__ __forceinline__ void publish_result(const TraceArgs& A, unsigned int ray, unsigned int n_lights, float t,
+                                               int obj, d3 pos, d3 vec, const double* X, int identity, int source) {
     if (MODE == 0) {
         d3 world;
         float d = hit_metric(X, identity, pos, vec, t, &world);
-        if (t != RT_MISS_T && (d < *best_d || (d == *best_d && *best_obj >= 0 && obj < *best_obj))) {
-            *best_d = d; *best_obj = obj;
-        }
+        if (t != RT_MISS_T && d < RT_MISS_T) atomicMin(&A.keys[ray], make_key(d, obj));
     } else {
-        if (t != RT_MISS_T && obj != source) *occluded = true;
+        if (t != RT_MISS_T && obj != source) {
+            const unsigned int hit = ray / n_lights, light = ray - hit * n_lights;
+            atomicOr(&A.occluded[(size_t)hit * A.occl_words + (light >> 5)], 1u << (light & 31));
+        }
     }
 }
 
-// The FP32 filter: false only when the reference-precision test of this (ray, triangle)
-// pair is certain to miss.  f = {n, d0 | S, s0 | T, t0 | U, u0}: the triangle's plane and its
-// three barycentric coordinates as affine functions with their margins folded in.
-// The triangle's 16 floats arrive in scalar registers.
+// The FP32 filter for one (ray, triangle) pair: false only when the reference-precision
+// test of the pair is certain to miss.  Record f (wave-uniform, in scalar registers):
+//   f[0..3]   unit normal n and d0 = n.v1
+//   f[4..6]   s as an affine function of the hit point's two coordinates OTHER than the
+//             normal's dominant axis (the third follows from the plane equation),
+//   f[7..9]   t likewise, f[10..12] u = 1 - s - t likewise; every offset includes the margin.
+// (pu, pv, vu, vv): those two coordinates of the ray origin and direction.
+// rlo / az: the query's thresholds (FilterParams).
+// Every comparison is false for NaN, so NaN never rejects.  A ray too parallel to the plane
+// needs no test of its own: the reference then misses unless the origin lies on the plane
+// (raytracer.cpp:319-325), which the last term keeps.
 __device__ __forceinline__ bool filter_keep(const v16f f, float px, float py, float pz, float vx, float vy, float vz,
-                                            const FilterParams fp) {
+                                            float pu, float pv, float vu, float vv, const float rlo, const float az) {
     float b = f[0] * vx;
     b = __builtin_fmaf(f[1], vy, b);
     b = __builtin_fmaf(f[2], vz, b);
@@ -160,24 +182,112 @@ __device__ __forceinline__ bool filter_keep(const v16f f, float px, float py, fl
     a = __builtin_fmaf(-f[1], py, a);
     a = __builtin_fmaf(-f[2], pz, a);
     const float r = a * __builtin_amdgcn_rcpf(b);
-    const float hx = __builtin_fmaf(r, vx, px);
-    const float hy = __builtin_fmaf(r, vy, py);
-    const float hz = __builtin_fmaf(r, vz, pz);
-    const float s = __builtin_fmaf(f[4], hx, __builtin_fmaf(f[5], hy, __builtin_fmaf(f[6], hz, f[7])));
-    const float t = __builtin_fmaf(f[8], hx, __builtin_fmaf(f[9], hy, __builtin_fmaf(f[10], hz, f[11])));
-    const float u = __builtin_fmaf(f[12], hx, __builtin_fmaf(f[13], hy, __builtin_fmaf(f[14], hz, f[15])));
+    const float hu = __builtin_fmaf(r, vu, pu);
+    const float hv = __builtin_fmaf(r, vv, pv);
+    const float s = __builtin_fmaf(f[4], hu, __builtin_fmaf(f[5], hv, f[6]));
+    const float t = __builtin_fmaf(f[7], hu, __builtin_fmaf(f[8], hv, f[9]));
+    const float u = __builtin_fmaf(f[10], hu, __builtin_fmaf(f[11], hv, f[12]));
     const float m = __builtin_fminf(__builtin_fminf(s, t), u);
-    // Every comparison is false for NaN, so NaN never rejects.  A ray too parallel to the
-    // plane (|b| below the reference's grazing threshold) needs no test of its own: the
-    // reference then misses unless the origin lies on the plane, which the last term keeps.
-    const bool reject = (m < 0.0f) | (r < fp.r_lo);
-    return (!reject) | (fabsf(a) <= fp.a_zero);
+    const bool reject = (m < 0.0f) | (r < rlo);
+    return (!reject) | (fabsf(a) <= az);
+}
+
+template <int RPL> struct FilterLane {
+    float px[RPL], py[RPL], pz[RPL], vx[RPL], vy[RPL], vz[RPL];
+    unsigned int on;     // bit r: candidates of slot r count (the slot holds a ray the filter may judge)
+};
+
+template <int AXIS> __device__ __forceinline__ float pick_u(float x, float y, float z) { return AXIS == 0 ? y : (AXIS == 1 ? z : x); }
+template <int AXIS> __device__ __forceinline__ float pick_v(float x, float y, float z) { return AXIS == 0 ? z : (AXIS == 1 ? x : y); }
+
+// Appends the lane's staged candidates (LDS) to the pair list: one atomic per wave.
+template <int RPL>
+__device__ __forceinline__ void flush_candidates(const TraceArgs& A, const unsigned short* my_cand, int n_cand, int cbeg,
+                                                 unsigned int ray0, unsigned int n_rays, int lane) {
+    constexpr int SLOT_SHIFT = RT_SLOT_SHIFT(RPL);
+    // inclusive prefix sum of n_cand over the wave
+    int incl = n_cand;
+    for (int off = 1; off < RT_WAVE; off <<= 1) {
+        int up = __shfl_up(incl, off);
+        if (lane >= off) incl += up;
+    }
+    const int total = __shfl(incl, RT_WAVE - 1);
+    unsigned int base = 0;
+    if (lane == 0) base = atomicAdd(A.pair_count, (unsigned int)total);
+    base = __shfl(base, 0);
+    if (base + (unsigned int)total > A.pair_cap || base + (unsigned int)total < base) {
+        // list full: the surplus is dropped and every ray of this lane gets the full scan instead
+#pragma unroll
+        for (int r = 0; r < RPL; r++) {
+            const unsigned int ray = ray0 + r * RT_WAVE;
+            if (ray < n_rays && n_cand > 0) A.ray_flags[ray] = 1;
+        }
+        return;
+    }
+    unsigned long long* out = A.pairs + base + (unsigned int)(incl - n_cand);
+    for (int k = 0; k < n_cand; k++) {
+        const unsigned int e = my_cand[k * RT_BLOCK];
+        const unsigned int r = e >> SLOT_SHIFT;
+        const unsigned int slot = (unsigned int)cbeg + (e & ((1u << SLOT_SHIFT) - 1u));
+        out[k] = ((unsigned long long)(ray0 + r * RT_WAVE) << 32) | slot;
+    }
+}
+
+// Filter loop over the regular triangles [abeg, aend) whose normals share the dominant axis AXIS.
+template <int MODE, int RPL, int AXIS>
+__device__ __forceinline__ void filter_range(const cv16f* filt, const TraceArgs& A, const FilterLane<RPL>& L,
+                                             const FilterParams fp, int abeg, int aend, unsigned short* my_cand,
+                                             unsigned int ray0, unsigned int n_rays, int lane) {
+    constexpr int SLOT_SHIFT = RT_SLOT_SHIFT(RPL);
+    constexpr int CHUNK = 1 << SLOT_SHIFT;
+    float pu[RPL], pv[RPL], vu[RPL], vv[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; r++) {
+        pu[r] = pick_u<AXIS>(L.px[r], L.py[r], L.pz[r]); pv[r] = pick_v<AXIS>(L.px[r], L.py[r], L.pz[r]);
+        vu[r] = pick_u<AXIS>(L.vx[r], L.vy[r], L.vz[r]); vv[r] = pick_v<AXIS>(L.vx[r], L.vy[r], L.vz[r]);
+    }
+    for (int cbeg = abeg; cbeg < aend; cbeg += CHUNK) {
+        const int cend = min(cbeg + CHUNK, aend);
+        int n_cand = 0;
+        for (int j0 = cbeg; j0 < cend; j0 += RT_BATCH) {
+            const int jn = min(j0 + RT_BATCH, cend);
+            // The record of triangle j+1 is requested before triangle j is evaluated
+            // (the array carries one padding record, so j+1 is always readable).
+            v16f cur = filt[j0];
+            for (int j = j0; j < jn; j++) {
+                const v16f nxt = filt[j + 1];
+                bool keep[RPL], any = false;
+#pragma unroll
+                for (int r = 0; r < RPL; r++) {
+                    keep[r] = filter_keep(cur, L.px[r], L.py[r], L.pz[r], L.vx[r], L.vy[r], L.vz[r],
+                                          pu[r], pv[r], vu[r], vv[r], fp.r_lo, fp.a_zero);
+                    any |= keep[r];
+                }
+                if (any) {               // rarely true for any lane of the wave
+#pragma unroll
+                    for (int r = 0; r < RPL; r++) {
+                        if (keep[r] && ((L.on >> r) & 1u)) {
+                            my_cand[n_cand * RT_BLOCK] = (unsigned short)((j - cbeg) | (r << SLOT_SHIFT));
+                            n_cand++;
+                        }
+                    }
+                }
+                cur = nxt;
+            }
+            // Flush when some lane could overflow its staging slots during the next batch,
+            // and at the end of the chunk (entries are relative to the chunk base).
+            const bool last = jn >= cend;
+            if (__any(n_cand > RT_CAND_CAP - RT_BATCH * RPL) || (last && __any(n_cand > 0))) {
+                flush_candidates<RPL>(A, my_cand, n_cand, cbeg, ray0, n_rays, lane);
+                n_cand = 0;
+            }
+        }
+    }
 }
 
 template <int MODE, int RPL>
-__global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_MIN_WAVES)
-k_trace(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, const TriExact* __restrict__ exact,
-        TraceArgs A) {
+__global__ void __launch_bounds__(RT_BLOCK)
+k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, TraceArgs A) {
     // The filter records are never written while a kernel runs: reading them through the
     // constant address space lets the compiler use scalar loads (s_load_dwordx16).
     const cv16f* filt = (const cv16f*)filt_global;
@@ -187,212 +297,216 @@ k_trace(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, c
     // derived from it (task, triangle index) stays in scalar registers.
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / RT_WAVE);
     unsigned short* my_cand = cand + wave_in_block * RT_WAVE + lane;   // entry k at my_cand[k * RT_BLOCK]
-    const int n_waves = gridDim.x * (RT_BLOCK / RT_WAVE);
-    const int wave_id = blockIdx.x * (RT_BLOCK / RT_WAVE) + wave_in_block;
-    constexpr int RAYS_PER_TASK = RT_WAVE * RPL;
+    const unsigned int n_waves = gridDim.x * (RT_BLOCK / RT_WAVE);
+    const unsigned int wave_id = blockIdx.x * (RT_BLOCK / RT_WAVE) + wave_in_block;
+    constexpr unsigned int RAYS_PER_TASK = RT_WAVE * RPL;
 
-    const int n_lights = sc->n_lights;
+    const unsigned int n_lights = sc->n_lights;
     // the queue length is the same for every lane: keep it (and all loop bounds derived from it) scalar
     const unsigned int n_hits = __builtin_amdgcn_readfirstlane(*A.n_items);
-    const unsigned long long n_rays = (MODE == 0) ? n_hits : (unsigned long long)n_hits * n_lights;
-    const unsigned int n_ray_blocks = (unsigned int)((n_rays + RAYS_PER_TASK - 1) / RAYS_PER_TASK);
-    const int NR = sc->n_regular, NI = sc->n_irregular, NS = sc->n_spheres;
+    const unsigned int n_rays = (MODE == 0) ? n_hits : n_hits * n_lights;
+    const unsigned int n_ray_blocks = (n_rays + RAYS_PER_TASK - 1) / RAYS_PER_TASK;
+    const int NR = sc->n_regular;
+    if (NR == 0 || n_ray_blocks == 0) return;
     // Split the triangle range over several waves when there are too few rays to fill the chip.
-    int max_split = (NR + 2047) / 2048;
-    if (max_split < 1) max_split = 1;
+    int max_split = (NR + 1023) / 1024;
     int split = 1;
-    if (n_ray_blocks > 0 && n_ray_blocks < 2u * n_waves) {
-        split = (2 * n_waves + n_ray_blocks - 1) / n_ray_blocks;
+    if (n_ray_blocks < 2u * n_waves) {
+        split = (int)((2u * n_waves + n_ray_blocks - 1) / n_ray_blocks);
         if (split > max_split) split = max_split;
     }
-    const unsigned int n_tasks = n_ray_blocks * (unsigned int)split;   // < 2^31: n_ray_blocks * split <= ~4 * n_waves or n_ray_blocks
-    const float eps = (MODE == 0) ? sc->eps : sc->shadow_eps;
+    const unsigned int n_tasks = n_ray_blocks * (unsigned int)split;
     const FilterParams fp = (MODE == 0) ? sc->fp_closest : sc->fp_shadow;
     const float ob = sc->origin_bound, vb = sc->dir_len2_bound;
-    const int n_groups = (MODE == 0) ? sc->n_groups : 1;
-    unsigned int exact_total = 0;
+    const int n_groups = sc->n_groups;
 
     for (unsigned int task = wave_id; task < n_tasks; task += n_waves) {
         // integer division goes through the vector ALU; its result is still wave-uniform
         const int part = __builtin_amdgcn_readfirstlane((int)(task / n_ray_blocks));
         const unsigned int rb = task - (unsigned int)part * n_ray_blocks;
-        const unsigned long long ray0 = (unsigned long long)rb * RAYS_PER_TASK + lane;   // slot r: ray0 + r * 64
-        float best_d[RPL];
-        int best_obj[RPL];
-        bool done[RPL], invalid[RPL];     // done: slot needs no more tests (no ray, or already occluded)
+        const unsigned int ray0 = rb * RAYS_PER_TASK + lane;          // slot r: ray0 + r * 64
+        bool have_rays = false;
+        FilterLane<RPL> L;
 #pragma unroll
-        for (int r = 0; r < RPL; r++) {
-            best_d[r] = RT_MISS_T; best_obj[r] = -1;
-            invalid[r] = ray0 + (unsigned long long)r * RT_WAVE >= n_rays;
-            done[r] = invalid[r];
-        }
-
-        // ---- spheres and irregular triangles: always in reference precision (first part only) ----
-        if (part == 0 && NS + NI > 0) {
-#pragma unroll
-            for (int r = 0; r < RPL; r++) {
-                if (done[r]) continue;
-                d3 wpos, wvec;
-                int source;
-                load_world_ray<MODE>(A, sc, ray0 + (unsigned long long)r * RT_WAVE, n_lights, &wpos, &wvec, &source);
-                bool occ = false;
-                for (int s = 0; s < NS; s++) {
-                    const SphereRec& S = sc->spheres[s];
-                    const double* X = sc->xforms + 48 * (size_t)S.xf;
-                    d3 pos = wpos, vec = wvec;
-                    const int ident = (MODE == 0) ? S.identity : 1;   // shadow rays are never transformed (raytracer.cpp:553)
-                    to_object_space(X, ident, &pos, &vec);
-                    float t = sph_intersect_exact(S, pos, vec, eps);
-                    fold_result<MODE>(t, S.obj, pos, vec, X, ident, source, &best_d[r], &best_obj[r], &occ);
-                    exact_total++;
-                }
-                for (int g = 0; g < n_groups; g++) {
-                    int ibeg = NR, iend = NR + NI, ident = 1;
-                    const double* X = sc->xforms;
-                    if (MODE == 0) {
-                        const Group& G = sc->groups[g];
-                        ibeg = G.ibeg; iend = G.iend; ident = G.identity;
-                        X = sc->xforms + 48 * (size_t)G.xf;
-                    }
-                    d3 pos = wpos, vec = wvec;
-                    to_object_space(X, ident, &pos, &vec);
-                    for (int i = ibeg; i < iend; i++) {
-                        float t = tri_intersect_exact(exact[i], pos, vec, eps);
-                        fold_result<MODE>(t, exact[i].obj, pos, vec, X, ident, source, &best_d[r], &best_obj[r], &occ);
-                        exact_total++;
-                    }
-                }
-                if (MODE == 1 && occ) done[r] = true;
-            }
-        }
-
-        // ---- regular triangles, group by group ----
+        for (int k = 0; k < RPL; k++) { L.px[k] = L.py[k] = L.pz[k] = L.vx[k] = L.vy[k] = 0.f; L.vz[k] = 1.f; }
         for (int g = 0; g < n_groups; g++) {
-            int fbeg = 0, fend = NR, ident = 1;
-            const double* X = sc->xforms;
-            if (MODE == 0) {
-                // group records are the same for every lane: keep the bounds in scalar registers
-                const Group& G = sc->groups[g];
-                fbeg = __builtin_amdgcn_readfirstlane(G.fbeg); fend = __builtin_amdgcn_readfirstlane(G.fend);
-                ident = __builtin_amdgcn_readfirstlane(G.identity);
-                X = sc->xforms + 48 * (size_t)__builtin_amdgcn_readfirstlane(G.xf);
-            }
-            // this wave's share of the group's regular triangles
-            const int glen = fend - fbeg;
-            const int per_part = __builtin_amdgcn_readfirstlane((glen + split - 1) / split);
-            const int pbeg = fbeg + part * per_part;
-            const int pend = min(fend, pbeg + per_part);
-            if (pbeg >= pend) continue;
-
-            // FP32 copies of the rays in this group's object space
-            float px[RPL], py[RPL], pz[RPL], vx[RPL], vy[RPL], vz[RPL];
-            bool force[RPL];              // test everything exactly for this slot
+            // group records are the same for every lane: keep the bounds in scalar registers
+            const Group& G = sc->groups[g];
+            int fax[4];
 #pragma unroll
-            for (int r = 0; r < RPL; r++) {
-                d3 pos = mk3(0, 0, 0), vec = mk3(0, 0, 1);
-                int source;
-                if (!invalid[r]) {
-                    load_world_ray<MODE>(A, sc, ray0 + (unsigned long long)r * RT_WAVE, n_lights, &pos, &vec, &source);
+            for (int k = 0; k < 4; k++) fax[k] = __builtin_amdgcn_readfirstlane(G.fax[k]);
+            // Shadow rays are tested against every group's untransformed geometry
+            // (raytracer.cpp:553): for them the groups only delimit the axis ranges.
+            const int ident = (MODE == 0) ? __builtin_amdgcn_readfirstlane(G.identity) : 1;
+            const double* X = sc->xforms + 48 * (size_t)__builtin_amdgcn_readfirstlane(G.xf);
+            if (fax[0] >= fax[3]) continue;
+            // FP32 copies of the lane's rays in this group's object space
+            if (MODE == 0 || !have_rays) {
+                have_rays = true;
+                L.on = 0;
+                // A real loop (not unrolled): one ray's double-precision temporaries are dead before
+                // the next ray's are born, so this prologue does not set the kernel's register count.
+                // The results are routed into the (statically indexed) register arrays by selects.
+#pragma unroll 1
+                for (int r = 0; r < RPL; r++) {
+                    // A slot past the end of the queue mirrors the queue's last ray: its candidates are
+                    // dropped (bit r of L.on stays clear), so no per-slot thresholds are needed.
+                    const unsigned int ray = ray0 + r * RT_WAVE;
+                    const bool valid = ray < n_rays;
+                    d3 pos, vec;
+                    int source;
+                    load_world_ray<MODE>(A, sc, valid ? ray : n_rays - 1, n_lights, &pos, &vec, &source);
                     to_object_space(X, ident, &pos, &vec);
-                }
-                px[r] = (float)pos.x; py[r] = (float)pos.y; pz[r] = (float)pos.z;
-                vx[r] = (float)vec.x; vy[r] = (float)vec.y; vz[r] = (float)vec.z;
-                // Outside the bounds the margins were derived for (or NaN): no filtering.
-                const bool trusted = fabsf(px[r]) <= ob && fabsf(py[r]) <= ob && fabsf(pz[r]) <= ob &&
-                                     (vx[r] * vx[r] + vy[r] * vy[r] + vz[r] * vz[r]) <= vb;
-                force[r] = A.force_exact || !trusted;
-            }
-
-            for (int cbeg = pbeg; cbeg < pend; cbeg += RT_CHUNK) {
-                const int cend = min(cbeg + RT_CHUNK, pend);
-                int n_cand = 0;
-                for (int j0 = cbeg; j0 < cend; j0 += RT_BATCH) {
-                    const int jn = min(j0 + RT_BATCH, cend);
-                    if (MODE == 1) {
-                        bool all_done = true;
-#pragma unroll
-                        for (int r = 0; r < RPL; r++) all_done = all_done && done[r];
-                        if (!__any(!all_done)) break;
+                    float fx = (float)pos.x, fy = (float)pos.y, fz = (float)pos.z;
+                    float gx = (float)vec.x, gy = (float)vec.y, gz = (float)vec.z;
+                    // Outside the bounds the margins were derived for (or NaN): the ray takes the
+                    // full reference-precision scan of k_brute instead of the filter.
+                    const bool trusted = fabsf(fx) <= ob && fabsf(fy) <= ob && fabsf(fz) <= ob &&
+                                         (gx * gx + gy * gy + gz * gz) <= vb;
+                    if (!trusted) {
+                        if (valid && part == 0) A.ray_flags[ray] = 1;
+                        fx = 0.f; fy = 0.f; fz = 0.f; gx = 0.f; gy = 0.f; gz = 1.f;
                     }
-                    // The record of triangle j+1 is requested before triangle j is evaluated
-                    // (the array carries one padding record, so j+1 is always readable).
-                    v16f cur = filt[j0];
-#pragma unroll 2
-                    for (int j = j0; j < jn; j++) {
-                        const v16f nxt = filt[j + 1];
-                        bool c[RPL], any = false;
+                    if (valid && trusted) L.on |= 1u << r;
 #pragma unroll
-                        for (int r = 0; r < RPL; r++) {
-                            c[r] = (filter_keep(cur, px[r], py[r], pz[r], vx[r], vy[r], vz[r], fp) | force[r]) & !done[r];
-                            any |= c[r];
-                        }
-                        // one (rarely taken) region per triangle for all of the lane's rays
-                        if (any) {
-                            // The entry is built from a SCALAR register here, inside the branch;
-                            // otherwise the compiler moves the whole triangle counter (and with it
-                            // the address of every record load) to the vector ALU.
-                            unsigned int entry;
-                            asm volatile("v_mov_b32 %0, %1" : "=v"(entry) : "s"(j - cbeg));
-#pragma unroll
-                            for (int r = 0; r < RPL; r++) {
-                                if (c[r]) {
-                                    my_cand[n_cand * RT_BLOCK] = (unsigned short)(entry | (r << RT_SLOT_SHIFT));
-                                    n_cand++;
-                                }
-                            }
-                        }
-                        cur = nxt;
-                    }
-                    // Drain when some lane could overflow during the next batch, and at the end of the chunk.
-                    const bool last = jn >= cend;
-                    if (__any(n_cand > RT_CAND_CAP - RT_BATCH * RPL) || (last && __any(n_cand > 0))) {
-                        unsigned int dmask = 0;
-#pragma unroll
-                        for (int r = 0; r < RPL; r++) dmask |= done[r] ? (1u << r) : 0u;
-                        for (int k = 0; __any(k < n_cand); k++) {
-                            if (k >= n_cand) continue;
-                            const unsigned int e = my_cand[k * RT_BLOCK];
-                            const int r = (int)(e >> RT_SLOT_SHIFT);
-                            if ((dmask >> r) & 1u) continue;
-                            const int j = cbeg + (int)(e & ((1u << RT_SLOT_SHIFT) - 1u));
-                            // the ray in reference precision, re-read and re-transformed on demand
-                            d3 pos, vec;
-                            int source;
-                            load_world_ray<MODE>(A, sc, ray0 + (unsigned long long)r * RT_WAVE, n_lights, &pos, &vec, &source);
-                            to_object_space(X, ident, &pos, &vec);
-                            const TriExact& T = exact[j];
-                            const float t = tri_intersect_exact(T, pos, vec, eps);
-                            exact_total++;
-                            bool occ = false;
-#pragma unroll
-                            for (int rr = 0; rr < RPL; rr++)
-                                if (rr == r) fold_result<MODE>(t, T.obj, pos, vec, X, ident, source, &best_d[rr], &best_obj[rr], &occ);
-                            if (MODE == 1 && occ) dmask |= 1u << r;
-                        }
-#pragma unroll
-                        for (int r = 0; r < RPL; r++) done[r] = (dmask >> r) & 1u;
-                        n_cand = 0;
+                    for (int k = 0; k < RPL; k++) {
+                        const bool here = (k == r);
+                        L.px[k] = here ? fx : L.px[k]; L.py[k] = here ? fy : L.py[k]; L.pz[k] = here ? fz : L.pz[k];
+                        L.vx[k] = here ? gx : L.vx[k]; L.vy[k] = here ? gy : L.vy[k]; L.vz[k] = here ? gz : L.vz[k];
                     }
                 }
             }
-        }
-
-        // ---- publish ----
+            // each part takes its share of every axis range
 #pragma unroll
-        for (int r = 0; r < RPL; r++) {
-            if (invalid[r]) continue;
-            const unsigned long long ray = ray0 + (unsigned long long)r * RT_WAVE;
-            if (MODE == 0) {
-                if (best_obj[r] >= 0) atomicMin(&A.keys[ray], make_key(best_d[r], best_obj[r]));
-            } else if (done[r]) {
-                const unsigned int hit = (unsigned int)(ray / n_lights), light = (unsigned int)(ray % n_lights);
-                atomicOr(&A.occluded[(size_t)hit * A.occl_words + (light >> 5)], 1u << (light & 31));
+            for (int axis = 0; axis < 3; axis++) {
+                const int alen = fax[axis + 1] - fax[axis];
+                const int per_part = __builtin_amdgcn_readfirstlane((alen + split - 1) / split);
+                const int abeg = fax[axis] + part * per_part;
+                const int aend = min(fax[axis + 1], abeg + per_part);
+                if (abeg >= aend) continue;
+                if (axis == 0) filter_range<MODE, RPL, 0>(filt, A, L, fp, abeg, aend, my_cand, ray0, n_rays, lane);
+                if (axis == 1) filter_range<MODE, RPL, 1>(filt, A, L, fp, abeg, aend, my_cand, ray0, n_rays, lane);
+                if (axis == 2) filter_range<MODE, RPL, 2>(filt, A, L, fp, abeg, aend, my_cand, ray0, n_rays, lane);
             }
         }
     }
-    // one counter update per wave
-    for (int off = 32; off > 0; off >>= 1) exact_total += __shfl_xor(exact_total, off);
-    if (lane == 0 && exact_total) atomicAdd(&A.counters->exact_tests, (unsigned long long)exact_total);
+}
+
+// One thread per listed (ray, triangle) pair.
+template <int MODE>
+__global__ void __launch_bounds__(RT_BLOCK)
+k_exact_pairs(const DevScene* __restrict__ sc, const TriExact* __restrict__ exact, TraceArgs A) {
+    const unsigned int listed = *A.pair_count;
+    const unsigned int n = listed < A.pair_cap ? listed : A.pair_cap;
+    const unsigned int n_lights = sc->n_lights;
+    const float eps = (MODE == 0) ? sc->eps : sc->shadow_eps;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned long long pr = A.pairs[i];
+        const unsigned int ray = (unsigned int)(pr >> 32), slot = (unsigned int)pr;
+        const TriExact& T = exact[slot];
+        int ident = 1;
+        const double* X = sc->xforms;
+        if (MODE == 0) {
+            const Group& G = sc->groups[T.grp];
+            ident = G.identity;
+            X = sc->xforms + 48 * (size_t)G.xf;
+        }
+        d3 pos, vec;
+        int source;
+        load_world_ray<MODE>(A, sc, ray, n_lights, &pos, &vec, &source);
+        to_object_space(X, ident, &pos, &vec);
+        const float t = tri_intersect_exact(T, pos, vec, eps);
+        publish_result<MODE>(A, ray, n_lights, t, T.obj, pos, vec, X, ident, source);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&A.counters->exact_tests, (unsigned long long)n);
+}
+
+// One ray per lane, every primitive the filter does not cover, in reference arithmetic.
+template <int MODE>
+__global__ void __launch_bounds__(RT_BLOCK)
+k_brute(const DevScene* __restrict__ sc, const TriExact* __restrict__ exact, TraceArgs A) {
+    const int lane = threadIdx.x & (RT_WAVE - 1);
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / RT_WAVE);
+    const unsigned int n_waves = gridDim.x * (RT_BLOCK / RT_WAVE);
+    const unsigned int wave_id = blockIdx.x * (RT_BLOCK / RT_WAVE) + wave_in_block;
+    const unsigned int n_lights = sc->n_lights;
+    const unsigned int n_hits = __builtin_amdgcn_readfirstlane(*A.n_items);
+    const unsigned int n_rays = (MODE == 0) ? n_hits : n_hits * n_lights;
+    const unsigned int n_ray_blocks = (n_rays + RT_WAVE - 1) / RT_WAVE;
+    if (n_ray_blocks == 0) return;
+    const int NR = sc->n_regular, NI = sc->n_irregular, NS = sc->n_spheres;
+    int max_split = (NR + 255) / 256;
+    if (max_split < 1) max_split = 1;
+    int split = 1;
+    if (n_ray_blocks < 2u * n_waves) {
+        split = (int)((2u * n_waves + n_ray_blocks - 1) / n_ray_blocks);
+        if (split > max_split) split = max_split;
+    }
+    const unsigned int n_tasks = n_ray_blocks * (unsigned int)split;
+    const float eps = (MODE == 0) ? sc->eps : sc->shadow_eps;
+    const int n_groups = (MODE == 0) ? sc->n_groups : 1;
+    unsigned int n_exact = 0;
+
+    for (unsigned int task = wave_id; task < n_tasks; task += n_waves) {
+        const int part = __builtin_amdgcn_readfirstlane((int)(task / n_ray_blocks));
+        const unsigned int rb = task - (unsigned int)part * n_ray_blocks;
+        const unsigned int ray = rb * RT_WAVE + lane;
+        const bool valid = ray < n_rays;
+        const bool scan = valid && (A.scan_all || A.ray_flags[ray] != 0);
+        const bool any_scan = __any(scan);
+        if (!any_scan && (part != 0 || NS + NI == 0)) continue;
+        d3 wpos = mk3(0, 0, 0), wvec = mk3(0, 0, 1);
+        int source = -1;
+        if (valid) load_world_ray<MODE>(A, sc, ray, n_lights, &wpos, &wvec, &source);
+
+        if (part == 0 && valid) {
+            for (int s = 0; s < NS; s++) {
+                const SphereRec& S = sc->spheres[s];
+                const double* X = sc->xforms + 48 * (size_t)S.xf;
+                d3 pos = wpos, vec = wvec;
+                const int ident = (MODE == 0) ? S.identity : 1;   // shadow rays are never transformed (raytracer.cpp:553)
+                to_object_space(X, ident, &pos, &vec);
+                const float t = sph_intersect_exact(S, pos, vec, eps);
+                publish_result<MODE>(A, ray, n_lights, t, S.obj, pos, vec, X, ident, source);
+                n_exact++;
+            }
+        }
+        for (int g = 0; g < n_groups; g++) {
+            int fbeg = 0, fend = NR, ibeg = NR, iend = NR + NI, ident = 1;
+            const double* X = sc->xforms;
+            if (MODE == 0) {
+                const Group& G = sc->groups[g];
+                fbeg = __builtin_amdgcn_readfirstlane(G.fax[0]); fend = __builtin_amdgcn_readfirstlane(G.fax[3]);
+                ibeg = __builtin_amdgcn_readfirstlane(G.ibeg); iend = __builtin_amdgcn_readfirstlane(G.iend);
+                ident = __builtin_amdgcn_readfirstlane(G.identity);
+                X = sc->xforms + 48 * (size_t)__builtin_amdgcn_readfirstlane(G.xf);
+            }
+            d3 pos = wpos, vec = wvec;
+            to_object_space(X, ident, &pos, &vec);
+            if (part == 0 && valid) {
+                for (int i = ibeg; i < iend; i++) {
+                    const float t = tri_intersect_exact(exact[i], pos, vec, eps);
+                    publish_result<MODE>(A, ray, n_lights, t, exact[i].obj, pos, vec, X, ident, source);
+                    n_exact++;
+                }
+            }
+            if (any_scan) {
+                const int glen = fend - fbeg;
+                const int per_part = __builtin_amdgcn_readfirstlane((glen + split - 1) / split);
+                const int pbeg = fbeg + part * per_part;
+                const int pend = min(fend, pbeg + per_part);
+                if (scan) {
+                    for (int j = pbeg; j < pend; j++) {
+                        const float t = tri_intersect_exact(exact[j], pos, vec, eps);
+                        publish_result<MODE>(A, ray, n_lights, t, exact[j].obj, pos, vec, X, ident, source);
+                        n_exact++;
+                    }
+                }
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) n_exact += __shfl_xor(n_exact, off);
+    if (lane == 0 && n_exact) atomicAdd(&A.counters->exact_tests, (unsigned long long)n_exact);
 }
 
 // ---------------------------------------------------------------------------
