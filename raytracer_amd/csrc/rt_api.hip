@@ -173,7 +173,7 @@ int ensure_workspace(rt_ctx* c) {
     // room for 16 listed pairs per ray of the largest launch (a few are typical), 8 B each
     c->pair_cap = std::min<size_t>(std::max<size_t>(shadow_rays * 16, 1u << 20), 1u << 28);
     HIP_TRY(c->pairs.alloc(c->pair_cap));
-    HIP_TRY(c->pair_count.alloc(1));
+    HIP_TRY(c->pair_count.alloc(2));      // [0] pairs listed, [1] k_filter's task counter
     return 0;
 }
 
@@ -223,8 +223,9 @@ template <int MODE>
 int launch_trace(rt_ctx* c, TraceArgs A, hipStream_t st) {
     const DevScene* dsc = c->d_scene.p;
     A.ray_flags = c->ray_flags.p; A.pairs = c->pairs.p; A.pair_count = c->pair_count.p;
+    A.task_counter = c->pair_count.p + 1;
     A.pair_cap = (unsigned int)c->pair_cap; A.counters = c->counters.p; A.scan_all = c->force_exact;
-    HIP_TRY(hipMemsetAsync(c->pair_count.p, 0, sizeof(unsigned int), st));
+    HIP_TRY(hipMemsetAsync(c->pair_count.p, 0, 2 * sizeof(unsigned int), st));
     HIP_TRY(hipMemsetAsync(c->ray_flags.p, 0, c->ray_flags.n, st));
     if (!c->force_exact && c->hs.n_regular > 0) {
         Timed t(c, st, MODE);

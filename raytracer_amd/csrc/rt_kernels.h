@@ -110,6 +110,7 @@ struct TraceArgs {
     uint8_t* ray_flags;                  // per ray: 1 = k_brute must scan every triangle for it
     unsigned long long* pairs;           // (ray << 32) | exact-record slot
     unsigned int* pair_count;            // pairs appended so far (may run past pair_cap: the surplus is dropped)
+    unsigned int* task_counter;          // k_filter: next task to hand out (zeroed before the launch)
     unsigned int pair_cap;
     DevCounters* counters;
 };
@@ -298,7 +299,6 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / RT_WAVE);
     unsigned short* my_cand = cand + wave_in_block * RT_WAVE + lane;   // entry k at my_cand[k * RT_BLOCK]
     const unsigned int n_waves = gridDim.x * (RT_BLOCK / RT_WAVE);
-    const unsigned int wave_id = blockIdx.x * (RT_BLOCK / RT_WAVE) + wave_in_block;
     constexpr unsigned int RAYS_PER_TASK = RT_WAVE * RPL;
 
     const unsigned int n_lights = sc->n_lights;
@@ -308,11 +308,13 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
     const unsigned int n_ray_blocks = (n_rays + RAYS_PER_TASK - 1) / RAYS_PER_TASK;
     const int NR = sc->n_regular;
     if (NR == 0 || n_ray_blocks == 0) return;
-    // Split the triangle range over several waves when there are too few rays to fill the chip.
-    int max_split = (NR + 1023) / 1024;
+    // Tasks = (block of 64*RPL rays) x (part of the triangle range), handed out through a
+    // global counter.  Enough parts that every wave gets several tasks: short tasks keep the
+    // chip full until the end of the launch.
+    int max_split = (NR + 511) / 512;
     int split = 1;
-    if (n_ray_blocks < 2u * n_waves) {
-        split = (int)((2u * n_waves + n_ray_blocks - 1) / n_ray_blocks);
+    if (n_ray_blocks < 8u * n_waves) {
+        split = (int)((8u * n_waves + n_ray_blocks - 1) / n_ray_blocks);
         if (split > max_split) split = max_split;
     }
     const unsigned int n_tasks = n_ray_blocks * (unsigned int)split;
@@ -320,7 +322,11 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
     const float ob = sc->origin_bound, vb = sc->dir_len2_bound;
     const int n_groups = sc->n_groups;
 
-    for (unsigned int task = wave_id; task < n_tasks; task += n_waves) {
+    for (;;) {
+        unsigned int task = 0;
+        if (lane == 0) task = atomicAdd(A.task_counter, 1u);
+        task = __builtin_amdgcn_readfirstlane(task);
+        if (task >= n_tasks) break;
         // integer division goes through the vector ALU; its result is still wave-uniform
         const int part = __builtin_amdgcn_readfirstlane((int)(task / n_ray_blocks));
         const unsigned int rb = task - (unsigned int)part * n_ray_blocks;
