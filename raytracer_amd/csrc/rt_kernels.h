@@ -25,6 +25,9 @@
 #define RT_WAVE 64
 #define RT_CAND_CAP 64          // per-lane candidate staging slots in LDS (shared by the lane's rays)
 #define RT_BATCH 4              // triangles filtered between two capacity checks
+#ifndef RT_FILTER_MIN_WAVES
+#define RT_FILTER_MIN_WAVES 1     // waves per SIMD the filter kernel is compiled for (a higher value caps its VGPRs)
+#endif
 #define RT_RPL 8                // rays per lane in the filter kernel
 // a staged candidate (u16) = triangle index relative to a chunk base | ray slot << shift
 #define RT_SLOT_SHIFT(RPL) ((RPL) <= 2 ? 15 : ((RPL) <= 4 ? 14 : 13))
@@ -287,7 +290,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const TraceArgs&
 }
 
 template <int MODE, int RPL>
-__global__ void __launch_bounds__(RT_BLOCK)
+__global__ void __launch_bounds__(RT_BLOCK, RT_FILTER_MIN_WAVES)
 k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, TraceArgs A) {
     // The filter records are never written while a kernel runs: reading them through the
     // constant address space lets the compiler use scalar loads (s_load_dwordx16).
