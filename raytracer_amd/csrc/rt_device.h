@@ -13,6 +13,7 @@
 struct d3 { double x, y, z; };
 
 typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(4))) const v16f cv16f;
 
 // Regular triangle, FP32 filter form: 16 floats (layout at filter_keep in rt_kernels.h).

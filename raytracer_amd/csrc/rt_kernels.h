@@ -177,32 +177,45 @@ __device__ __forceinline__ void publish_result(const TraceArgs& A, unsigned int 
 // Every comparison is false for NaN, so NaN never rejects.  A ray too parallel to the plane
 // needs no test of its own: the reference then misses unless the origin lies on the plane
 // (raytracer.cpp:319-325), which the last term keeps.
-__device__ __forceinline__ bool filter_keep(const v16f f, float px, float py, float pz, float vx, float vy, float vz,
-                                            float pu, float pv, float vu, float vv, const float rlo, const float az) {
-    float b = f[0] * vx;
-    b = __builtin_fmaf(f[1], vy, b);
-    b = __builtin_fmaf(f[2], vz, b);
-    float a = __builtin_fmaf(-f[0], px, f[3]);
-    a = __builtin_fmaf(-f[1], py, a);
-    a = __builtin_fmaf(-f[2], pz, a);
-    const float r = a * __builtin_amdgcn_rcpf(b);
-    const float hu = __builtin_fmaf(r, vu, pu);
-    const float hv = __builtin_fmaf(r, vv, pv);
-    const float s = __builtin_fmaf(f[4], hu, __builtin_fmaf(f[5], hv, f[6]));
-    const float t = __builtin_fmaf(f[7], hu, __builtin_fmaf(f[8], hv, f[9]));
-    const float u = __builtin_fmaf(f[10], hu, __builtin_fmaf(f[11], hv, f[12]));
-    const float m = __builtin_fminf(__builtin_fminf(s, t), u);
-    const bool reject = (m < 0.0f) | (r < rlo);
-    return (!reject) | (fabsf(a) <= az);
+// Two rays at a time: MI355X reaches its FP32 vector peak only through the packed
+// instructions (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth of FMAs per issue slot), so the
+// lane's rays are kept as float2 pairs and every multiply-add of the test is a packed one.
+// Reciprocal, min3 and the comparisons have no packed form and stay per ray.
+__device__ __forceinline__ void filter_keep2(const v16f f, v2f px, v2f py, v2f pz, v2f vx, v2f vy, v2f vz,
+                                             v2f pu, v2f pv, v2f vu, v2f vv, const float rlo, const float az,
+                                             bool* keep0, bool* keep1) {
+    const v2f n0 = {f[0], f[0]}, n1 = {f[1], f[1]}, n2 = {f[2], f[2]}, d0 = {f[3], f[3]};
+    v2f b = n0 * vx;
+    b = __builtin_elementwise_fma(n1, vy, b);
+    b = __builtin_elementwise_fma(n2, vz, b);
+    v2f a = __builtin_elementwise_fma(-n0, px, d0);
+    a = __builtin_elementwise_fma(-n1, py, a);
+    a = __builtin_elementwise_fma(-n2, pz, a);
+    const v2f rinv = {__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y)};
+    const v2f r = a * rinv;
+    const v2f hu = __builtin_elementwise_fma(r, vu, pu);
+    const v2f hv = __builtin_elementwise_fma(r, vv, pv);
+    const v2f c4 = {f[4], f[4]}, c5 = {f[5], f[5]}, c6 = {f[6], f[6]};
+    const v2f c7 = {f[7], f[7]}, c8 = {f[8], f[8]}, c9 = {f[9], f[9]};
+    const v2f c10 = {f[10], f[10]}, c11 = {f[11], f[11]}, c12 = {f[12], f[12]};
+    const v2f s = __builtin_elementwise_fma(c4, hu, __builtin_elementwise_fma(c5, hv, c6));
+    const v2f t = __builtin_elementwise_fma(c7, hu, __builtin_elementwise_fma(c8, hv, c9));
+    const v2f u = __builtin_elementwise_fma(c10, hu, __builtin_elementwise_fma(c11, hv, c12));
+    const float m0 = __builtin_fminf(__builtin_fminf(s.x, t.x), u.x);
+    const float m1 = __builtin_fminf(__builtin_fminf(s.y, t.y), u.y);
+    const bool reject0 = (m0 < 0.0f) | (r.x < rlo);
+    const bool reject1 = (m1 < 0.0f) | (r.y < rlo);
+    *keep0 = (!reject0) | (fabsf(a.x) <= az);
+    *keep1 = (!reject1) | (fabsf(a.y) <= az);
 }
 
-template <int RPL> struct FilterLane {
-    float px[RPL], py[RPL], pz[RPL], vx[RPL], vy[RPL], vz[RPL];
+template <int RPL> struct FilterLane {     // ray slots 2q and 2q+1 share a float2
+    v2f px[RPL / 2], py[RPL / 2], pz[RPL / 2], vx[RPL / 2], vy[RPL / 2], vz[RPL / 2];
     unsigned int on;     // bit r: candidates of slot r count (the slot holds a ray the filter may judge)
 };
 
-template <int AXIS> __device__ __forceinline__ float pick_u(float x, float y, float z) { return AXIS == 0 ? y : (AXIS == 1 ? z : x); }
-template <int AXIS> __device__ __forceinline__ float pick_v(float x, float y, float z) { return AXIS == 0 ? z : (AXIS == 1 ? x : y); }
+template <int AXIS> __device__ __forceinline__ v2f pick_u(v2f x, v2f y, v2f z) { return AXIS == 0 ? y : (AXIS == 1 ? z : x); }
+template <int AXIS> __device__ __forceinline__ v2f pick_v(v2f x, v2f y, v2f z) { return AXIS == 0 ? z : (AXIS == 1 ? x : y); }
 
 // Appends the lane's staged candidates (LDS) to the pair list: one atomic per wave.
 template <int RPL>
@@ -244,11 +257,11 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const TraceArgs&
                                              unsigned int ray0, unsigned int n_rays, int lane) {
     constexpr int SLOT_SHIFT = RT_SLOT_SHIFT(RPL);
     constexpr int CHUNK = 1 << SLOT_SHIFT;
-    float pu[RPL], pv[RPL], vu[RPL], vv[RPL];
+    v2f pu[RPL / 2], pv[RPL / 2], vu[RPL / 2], vv[RPL / 2];
 #pragma unroll
-    for (int r = 0; r < RPL; r++) {
-        pu[r] = pick_u<AXIS>(L.px[r], L.py[r], L.pz[r]); pv[r] = pick_v<AXIS>(L.px[r], L.py[r], L.pz[r]);
-        vu[r] = pick_u<AXIS>(L.vx[r], L.vy[r], L.vz[r]); vv[r] = pick_v<AXIS>(L.vx[r], L.vy[r], L.vz[r]);
+    for (int q = 0; q < RPL / 2; q++) {
+        pu[q] = pick_u<AXIS>(L.px[q], L.py[q], L.pz[q]); pv[q] = pick_v<AXIS>(L.px[q], L.py[q], L.pz[q]);
+        vu[q] = pick_u<AXIS>(L.vx[q], L.vy[q], L.vz[q]); vv[q] = pick_v<AXIS>(L.vx[q], L.vy[q], L.vz[q]);
     }
     for (int cbeg = abeg; cbeg < aend; cbeg += CHUNK) {
         const int cend = min(cbeg + CHUNK, aend);
@@ -262,10 +275,10 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const TraceArgs&
                 const v16f nxt = filt[j + 1];
                 bool keep[RPL], any = false;
 #pragma unroll
-                for (int r = 0; r < RPL; r++) {
-                    keep[r] = filter_keep(cur, L.px[r], L.py[r], L.pz[r], L.vx[r], L.vy[r], L.vz[r],
-                                          pu[r], pv[r], vu[r], vv[r], fp.r_lo, fp.a_zero);
-                    any |= keep[r];
+                for (int q = 0; q < RPL / 2; q++) {
+                    filter_keep2(cur, L.px[q], L.py[q], L.pz[q], L.vx[q], L.vy[q], L.vz[q], pu[q], pv[q], vu[q], vv[q],
+                                 fp.r_lo, fp.a_zero, &keep[2 * q], &keep[2 * q + 1]);
+                    any |= keep[2 * q] | keep[2 * q + 1];
                 }
                 if (any) {               // rarely true for any lane of the wave
 #pragma unroll
@@ -337,7 +350,10 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
         bool have_rays = false;
         FilterLane<RPL> L;
 #pragma unroll
-        for (int k = 0; k < RPL; k++) { L.px[k] = L.py[k] = L.pz[k] = L.vx[k] = L.vy[k] = 0.f; L.vz[k] = 1.f; }
+        for (int k = 0; k < RPL / 2; k++) {
+            const v2f zero = {0.f, 0.f}, one = {1.f, 1.f};
+            L.px[k] = L.py[k] = L.pz[k] = L.vx[k] = L.vy[k] = zero; L.vz[k] = one;
+        }
         for (int g = 0; g < n_groups; g++) {
             // group records are the same for every lane: keep the bounds in scalar registers
             const Group& G = sc->groups[g];
@@ -379,9 +395,12 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                     if (valid && trusted) L.on |= 1u << r;
 #pragma unroll
                     for (int k = 0; k < RPL; k++) {
-                        const bool here = (k == r);
-                        L.px[k] = here ? fx : L.px[k]; L.py[k] = here ? fy : L.py[k]; L.pz[k] = here ? fz : L.pz[k];
-                        L.vx[k] = here ? gx : L.vx[k]; L.vy[k] = here ? gy : L.vy[k]; L.vz[k] = here ? gz : L.vz[k];
+                        if (k == r) {
+                            if (k & 1) { L.px[k / 2].y = fx; L.py[k / 2].y = fy; L.pz[k / 2].y = fz;
+                                         L.vx[k / 2].y = gx; L.vy[k / 2].y = gy; L.vz[k / 2].y = gz; }
+                            else { L.px[k / 2].x = fx; L.py[k / 2].x = fy; L.pz[k / 2].x = fz;
+                                   L.vx[k / 2].x = gx; L.vy[k / 2].x = gy; L.vz[k / 2].x = gz; }
+                        }
                     }
                 }
             }
