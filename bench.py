@@ -14,7 +14,7 @@ resident in HBM before the timed region.  Rank 0 prints one JSON line.
                 on the launch stream, against the 157.3 TFLOP/s FP32 vector peak.
   cpu_baseline  the unmodified reference renderer (oracle/_ref, kind "reference") -- or the
                 C restatement when that binary is absent (kind "port") -- timed on this
-                box's host cores on a 1/16 x 1/16 sub-grid of the same frame.
+                box's host cores on a 1/8 x 1/8 sub-grid of the same frame.
 """
 import argparse
 import json
@@ -47,9 +47,9 @@ def parse():
 
 def cpu_baseline(args, gpu_rays_fn):
     """Times the reference CPU renderer on a bounded sample of the same workload: the frame
-    at 1/16 x 1/16 resolution, which is exactly every 16th pixel of the full grid in x and y
+    at 1/8 x 1/8 resolution, which is exactly every 8th pixel of the full grid in x and y
     (the camera samples pixel corners: u = x / W)."""
-    w, h = max(1, args.width // 16), max(1, args.height // 16)
+    w, h = max(1, args.width // 8), max(1, args.height // 8)
     threads = min(16, os.cpu_count() or 1)
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_render")
     rays = gpu_rays_fn(w, h)
@@ -67,8 +67,31 @@ def cpu_baseline(args, gpu_rays_fn):
         secs = time.perf_counter() - t0
         kind = "port"
     return {"value": rays / secs / 1e6, "unit": "Mrays/s", "cores": threads, "kind": kind,
-            "sample": f"{w}x{h} sub-grid (every 16th pixel in x and y) of the {args.width}x{args.height} frame, "
+            "sample": f"{w}x{h} sub-grid (every 8th pixel in x and y) of the {args.width}x{args.height} frame, "
                       f"{rays} rays, {secs:.2f} s"}
+
+
+def measured_traffic(kernel_label, launches_per_frame):
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass of this same
+    command (profiles/*pmc_summary.csv, written by tools/pmc_passes.sh + tools/pmc_summary.py):
+    FETCH_SIZE is in KiB and reads half the bytes of a wide stream on gfx950 (doubled here),
+    WRITE_SIZE is in KiB and exact.  None when no such file exists."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.csv")))
+    if not files:
+        return None
+    want = "k_filter<0" if "<0>" in kernel_label else "k_filter<1"
+    fetch = write = None
+    for r in csv.DictReader(open(files[-1])):
+        if r["kernel"].startswith(want):
+            if r["counter"] == "FETCH_SIZE":
+                fetch = float(r["sum_over_dispatches"])
+            if r["counter"] == "WRITE_SIZE":
+                write = float(r["sum_over_dispatches"])
+    if fetch is None or write is None or launches_per_frame <= 0:
+        return None
+    return (2.0 * fetch + write) * 1024.0 / launches_per_frame   # the PMC pass profiles one frame
 
 
 def main():
@@ -76,7 +99,7 @@ def main():
     import torch
     import torch.distributed as dist
     from raytracer_amd import Scene, abi
-    from raytracer_amd.render import Renderer, gather_frame
+    from raytracer_amd.render import Renderer, TileGather
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -95,10 +118,11 @@ def main():
     frame = torch.zeros((args.height, args.width, 4), dtype=torch.uint8, device=dev)
     r.bind_frame(frame)
     stream = torch.cuda.current_stream().cuda_stream
+    exchange = TileGather(args.height, args.width, args.tile_rows, rank, world, dev, dist=dist, torch=torch)
 
     def step():
         r.render_tiles(rank, args.tile_rows, world, stream)
-        gather_frame(r, frame, args.tile_rows, rank, world, dist=dist, torch=torch)
+        exchange(frame)
 
     def fence():
         torch.cuda.synchronize()
@@ -161,7 +185,8 @@ def main():
                        "rays_per_frame": {"primary": n_primary // args.steps, "reflect": n_reflect // args.steps,
                                           "shadow": n_shadow // args.steps}},
             "roofline": {"bound": "valu_fp32", "kernel": dom, "achieved": achieved / 1e12, "peak": PEAK_FP32_VALU / 1e12,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU,
+                         "traffic": measured_traffic(dom, launches / max(1, args.steps)),
                          "kernel_ms_avg": ms / max(1, launches), "launches": launches,
                          "flop_per_test": flop_per_test, "tests_per_launch": tests / max(1, launches),
                          "both_filter_kernels_tflops": both / 1e12,

@@ -104,24 +104,41 @@ def pack_rows(frame, height, tile_rows, rank, world):
     return rows, max_tiles * tile_rows
 
 
-def gather_frame(renderer, frame, tile_rows, rank, world, dist=None, torch=None):
-    """End-of-frame exchange: every rank sends the rows of its tiles to rank 0, which
-    writes them into its frame.  `frame` is the rank's bound [H, W, 4] uint8 tensor;
-    the collective is torch.distributed.gather (RCCL on GPUs, gloo on CPU)."""
-    H, W = frame.shape[0], frame.shape[1]
-    rows, padded = pack_rows(frame, H, tile_rows, rank, world)
-    idx = torch.as_tensor(rows, dtype=torch.long, device=frame.device)
-    send = torch.zeros((padded, W, 4), dtype=torch.uint8, device=frame.device)
-    if len(rows):
-        send[: len(rows)] = frame.index_select(0, idx)
-    if world == 1:
+class TileGather:
+    """End-of-frame exchange, set up once per (frame size, tiling, rank): every rank sends the
+    rows of its tiles to rank 0, which writes them into its frame.  The collective is
+    torch.distributed.gather (RCCL over xGMI on GPUs, gloo on CPU).  Index tensors and
+    staging buffers are built here, not per frame."""
+
+    def __init__(self, height, width, tile_rows, rank, world, device, dist=None, torch=None):
+        self.rank, self.world, self.dist, self.torch = rank, world, dist, torch
+        rows, padded = pack_rows(None, height, tile_rows, rank, world)
+        self.n_rows = len(rows)
+        self.idx = torch.as_tensor(rows, dtype=torch.long, device=device)
+        self.send = torch.zeros((padded, width, 4), dtype=torch.uint8, device=device)
+        self.recv = None
+        self.peer_idx = {}
+        if rank == 0 and world > 1:
+            self.recv = [torch.empty_like(self.send) for _ in range(world)]
+            for r in range(1, world):
+                rrows, _ = pack_rows(None, height, tile_rows, r, world)
+                self.peer_idx[r] = torch.as_tensor(rrows, dtype=torch.long, device=device)
+
+    def __call__(self, frame):
+        if self.world == 1:
+            return frame
+        torch = self.torch
+        if self.n_rows:
+            torch.index_select(frame, 0, self.idx, out=self.send[: self.n_rows])
+        self.dist.gather(self.send, self.recv, dst=0)
+        if self.rank == 0:
+            for r, ridx in self.peer_idx.items():
+                if ridx.numel():
+                    frame.index_copy_(0, ridx, self.recv[r][: ridx.numel()])
         return frame
-    recv = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
-    dist.gather(send, recv, dst=0)
-    if rank == 0:
-        for r in range(1, world):
-            rrows, _ = pack_rows(frame, H, tile_rows, r, world)
-            if rrows:
-                ridx = torch.as_tensor(rrows, dtype=torch.long, device=frame.device)
-                frame.index_copy_(0, ridx, recv[r][: len(rrows)])
-    return frame
+
+
+def gather_frame(renderer, frame, tile_rows, rank, world, dist=None, torch=None):
+    """One-shot form of TileGather (builds the index tensors on every call)."""
+    g = TileGather(frame.shape[0], frame.shape[1], tile_rows, rank, world, frame.device, dist=dist, torch=torch)
+    return g(frame)

@@ -31,6 +31,7 @@ RENDERS = [
     ("journal.scene", 160, 120, 6), ("journal2.scene", 160, 120, 6),
     ("teapot.scene", 96, 54, 5), ("teapot.scene", 64, 36, 0),
     ("campanile_teddy.scene", 64, 36, 2), ("mixed_xf.scene", 160, 120, 4), ("normals.scene", 160, 120, 3),
+    ("synthetic_small.scene", 96, 54, 3),
 ]
 BLOBS = ["inputs/input-05", "inputs/input-07", "inputs/input-08", "inputs/input-09", "inputs/input-11",
          "ellipse.scene", "scene1.scene", "s3.scene", "mixed_xf.scene", "normals.scene"]

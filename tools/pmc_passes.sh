@@ -3,7 +3,7 @@
 # (counters of one hardware block must fit that block's slots).
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/pmc_r1
+OUT=gpurun_out/pmc_${TAG:-r1}
 mkdir -p $OUT
 CMD="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline"
 run() { name=$1; shift; timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- $CMD > $OUT/$name.log 2>&1 || { echo "pass $name failed"; tail -3 $OUT/$name.log; exit 1; }; echo "pass $name done"; }

@@ -21,4 +21,4 @@ for k in sorted(agg):
     if not k.startswith("k_"):
         continue
     for c in sorted(agg[k]):
-        print(f"{k},{c},{agg[k][c]:.0f}")
+        print(f"\"{k}\",{c},{agg[k][c]:.0f}")
