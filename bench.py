@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--tile-rows", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exact-only", action="store_true")
+    ap.add_argument("--no-lbvh", action="store_true", help="skip the extra LBVH-mode measurement")
     return ap.parse_args()
 
 
@@ -144,6 +145,36 @@ def main():
     st = r.stats()
     r.set_option(abi.RT_OPT_PROFILE, 0)
 
+    # The same frames again through the optional LBVH (same rays, same pixels; reported beside
+    # the brute-force headline, which is what the roofline describes).
+    lbvh = None
+    if not args.no_lbvh and not args.exact_only:
+        r.set_option(abi.RT_OPT_USE_BVH, 1)
+        step()
+        fence()
+        r.reset_stats()
+        fence()
+        tb = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        lb_elapsed = time.perf_counter() - tb
+        sb = r.stats()
+        r.set_option(abi.RT_OPT_USE_BVH, 0)
+        lb_rays = sb["rays_primary"] + sb["rays_reflect"] + sb["rays_shadow"]
+        if world > 1:
+            tt = torch.tensor([lb_elapsed, float(lb_rays)], dtype=torch.float64, device=dev)
+            mx = tt.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            sm = tt.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+            lb_elapsed, lb_rays_total = float(mx[0].item()), float(sm[1].item())
+        else:
+            lb_rays_total = float(lb_rays)
+        lbvh = {"value": lb_rays_total / lb_elapsed / 1e6, "unit": "Mrays/s", "ms_per_step": lb_elapsed / args.steps * 1e3,
+                "box_tests_per_ray": sb["bvh_node_tests"] / max(1, lb_rays),
+                "leaf_tests_per_ray": sb["bvh_leaf_tests"] / max(1, lb_rays),
+                "exact_retests_per_ray": sb["exact_tests"] / max(1, lb_rays),
+                "note": "frames byte-identical to brute force (tests/test_gpu_bvh.py)"}
+
     rays_local = st["rays_primary"] + st["rays_reflect"] + st["rays_shadow"]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -194,6 +225,8 @@ def main():
                          "reference_precision_kernels_ms_per_step": st["exact_ms"] / args.steps,
                          "exact_retests_per_ray": st["exact_tests"] / max(1, rays_local)},
         }
+        if lbvh is not None:
+            line["lbvh"] = lbvh
         if world == 1 and not args.no_cpu_baseline:
             def gpu_rays(w, h):
                 sc = Scene.load(args.scene, w, h, args.depth)

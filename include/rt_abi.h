@@ -89,7 +89,7 @@ typedef enum rt_option {
     RT_OPT_PROFILE = 2,      /* 1: bracket every trace-kernel launch with HIP events; the sums
                                 appear in rt_stats */
     RT_OPT_PASS_PIXELS = 3,  /* pixels traced per internal pass (bounds the workspace) */
-    RT_OPT_USE_BVH = 4       /* 1: nearest hits through the LBVH instead of the brute-force scan */
+    RT_OPT_USE_BVH = 4       /* 1: build (once) and use the LBVH in place of the brute-force triangle scan */
 } rt_option;
 
 /* Counters since rt_upload_scene or the last rt_reset_stats. */
@@ -101,6 +101,10 @@ typedef struct rt_stats {
     uint64_t closest_tests;  /* ray x primitive pairs scanned for nearest hits */
     uint64_t anyhit_tests;   /* ray x primitive pairs scanned for shadow rays */
     uint64_t exact_tests;    /* pairs evaluated in reference precision */
+    uint64_t bvh_node_tests; /* RT_OPT_USE_BVH: ray-box tests executed */
+    uint64_t bvh_leaf_tests; /* RT_OPT_USE_BVH: triangles reached at the leaves */
+    uint64_t in_plane_origin_hits; /* listed pairs that took the a == 0 branch of Triangle::intersection
+                                      (raytracer.cpp:319-321), the one case a box hierarchy cannot find */
     double closest_ms;       /* RT_OPT_PROFILE: summed duration of the nearest-hit filter kernel launches */
     double anyhit_ms;        /* RT_OPT_PROFILE: summed duration of the shadow filter kernel launches */
     double exact_ms;         /* RT_OPT_PROFILE: summed duration of the reference-precision kernels */

@@ -2,7 +2,13 @@
 // per-primitive precomputation, the pass scheduler that strings the kernels of
 // rt_kernels.h together, download and statistics.
 #include "rt_abi.h"
+#include <cstring>
+#include <string.h>
+
 #include "rt_kernels.h"
+#include "rt_bvh.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
 #include <cfloat>
@@ -111,6 +117,15 @@ struct rt_ctx {
     DevBuf<unsigned long long> pairs;
     DevBuf<unsigned int> pair_count;
     size_t pair_cap = 0;
+
+    // optional LBVH (RT_OPT_USE_BVH)
+    int use_bvh = 0;
+    bool bvh_built = false;
+    DevBuf<BvhNode> bvh_nodes;
+    DevBuf<GroupBvh> bvh_groups;
+    std::vector<Group> h_groups;
+    std::vector<float> h_centroid_box;   // per group: min[3], max[3] of the triangle centroids
+    double scene_bound = 0;
 
     // options
     int force_exact = 0;
@@ -229,8 +244,14 @@ int launch_trace(rt_ctx* c, TraceArgs A, hipStream_t st) {
     HIP_TRY(hipMemsetAsync(c->ray_flags.p, 0, c->ray_flags.n, st));
     if (!c->force_exact && c->hs.n_regular > 0) {
         Timed t(c, st, MODE);
-        hipLaunchKernelGGL((k_filter<MODE, RT_RPL>), dim3(c->filter_grid[MODE]), dim3(RT_BLOCK), 0, st, dsc,
-                           (const v16f*)c->tri_filt.p, A);
+        if (c->use_bvh) {
+            BvhCounters* bc = (BvhCounters*)&c->counters.p->bvh_node_tests;
+            hipLaunchKernelGGL(k_bvh_trace<MODE>, dim3(c->aux_grid), dim3(RT_BVH_BLOCK), 0, st, dsc,
+                               (const GroupBvh*)c->bvh_groups.p, (const float*)c->tri_filt.p, A, bc);
+        } else {
+            hipLaunchKernelGGL((k_filter<MODE, RT_RPL>), dim3(c->filter_grid[MODE]), dim3(RT_BLOCK), 0, st, dsc,
+                               (const v16f*)c->tri_filt.p, A);
+        }
         HIP_TRY(hipGetLastError());
         t.stop();
     }
@@ -243,6 +264,65 @@ int launch_trace(rt_ctx* c, TraceArgs A, hipStream_t st) {
     hipLaunchKernelGGL(k_brute<MODE>, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, dsc, (const TriExact*)c->tri_exact.p, A);
     HIP_TRY(hipGetLastError());
     t.stop();
+    return 0;
+}
+
+// Builds the per-group LBVHs on the device (once per context).
+int build_bvh(rt_ctx* c) {
+    if (c->bvh_built) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    const int NR = c->hs.n_regular;
+    const size_t G = c->h_groups.size();
+    HIP_TRY(c->bvh_nodes.alloc((size_t)std::max(NR, 1)));
+    std::vector<GroupBvh> hb(G);
+    int max_n = 0;
+    for (size_t g = 0; g < G; g++) max_n = std::max(max_n, c->h_groups[g].fax[3] - c->h_groups[g].fax[0]);
+    DevBuf<unsigned int> keys_in, keys_out, arrive;
+    DevBuf<int> vals_in, vals_out, parent_node, parent_leaf;
+    DevBuf<char> temp;
+    const size_t m = (size_t)std::max(max_n, 1);
+    HIP_TRY(keys_in.alloc(m)); HIP_TRY(keys_out.alloc(m)); HIP_TRY(vals_in.alloc(m)); HIP_TRY(vals_out.alloc(m));
+    HIP_TRY(parent_node.alloc(m)); HIP_TRY(parent_leaf.alloc(m)); HIP_TRY(arrive.alloc(m));
+    size_t temp_bytes = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, keys_in.p, keys_out.p, vals_in.p, vals_out.p, m, 0, 30));
+    HIP_TRY(temp.alloc(std::max<size_t>(temp_bytes, 16)));
+    const float pad_abs = (float)(64.0 * 1.1920928955078125e-7 * c->scene_bound);
+    size_t node_off = 0;
+    auto release_all = [&]() {
+        keys_in.release(); keys_out.release(); vals_in.release(); vals_out.release();
+        parent_node.release(); parent_leaf.release(); arrive.release(); temp.release();
+    };
+    for (size_t g = 0; g < G; g++) {
+        const Group& Gr = c->h_groups[g];
+        const int base = Gr.fax[0], n = Gr.fax[3] - Gr.fax[0];
+        hb[g].nodes = c->bvh_nodes.p + node_off;
+        hb[g].n = n;
+        hb[g].first_slot = base;
+        if (n <= 1) continue;
+        const float* bx = &c->h_centroid_box[6 * g];
+        float3 cmin = make_float3(bx[0], bx[1], bx[2]);
+        float3 cscale = make_float3(bx[3] > bx[0] ? 1.0f / (bx[3] - bx[0]) : 0.f, bx[4] > bx[1] ? 1.0f / (bx[4] - bx[1]) : 0.f,
+                                    bx[5] > bx[2] ? 1.0f / (bx[5] - bx[2]) : 0.f);
+        const int blocks = (n + 255) / 256;
+        hipLaunchKernelGGL(k_bvh_morton, dim3(blocks), dim3(256), 0, 0, (const TriExact*)c->tri_exact.p, base, n, cmin,
+                           cscale, keys_in.p, vals_in.p);
+        hipError_t e = rocprim::radix_sort_pairs(temp.p, temp_bytes, keys_in.p, keys_out.p, vals_in.p, vals_out.p,
+                                                 (size_t)n, 0, 30);
+        if (e != hipSuccess) { release_all(); return fail(RT_ERR_DEVICE, std::string("radix sort: ") + hipGetErrorString(e)); }
+        hipLaunchKernelGGL(k_bvh_hierarchy, dim3(blocks), dim3(256), 0, 0, (const unsigned int*)keys_out.p,
+                           (const int*)vals_out.p, n, base, c->bvh_nodes.p + node_off, parent_node.p, parent_leaf.p);
+        e = hipMemsetAsync(arrive.p, 0, (size_t)n * sizeof(unsigned int), 0);
+        hipLaunchKernelGGL(k_bvh_refit, dim3(blocks), dim3(256), 0, 0, (const TriExact*)c->tri_exact.p,
+                           (const int*)vals_out.p, n, base, c->bvh_nodes.p + node_off, (const int*)parent_node.p,
+                           (const int*)parent_leaf.p, arrive.p, pad_abs);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(0);
+        if (e != hipSuccess) { release_all(); return fail(RT_ERR_DEVICE, std::string("bvh build: ") + hipGetErrorString(e)); }
+        node_off += (size_t)(n - 1);
+    }
+    release_all();
+    HIP_TRY(c->bvh_groups.upload(hb));
+    c->bvh_built = true;
     return 0;
 }
 
@@ -498,6 +578,8 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
             double dBs = 2 * EPSF * wmax * (std::fabs(fuv) * le2 + fvv * le1) / std::fabs(fD) + 3 * EPSF;
             double dBt = 2 * EPSF * wmax * (std::fabs(fuv) * le1 + fuu * le2) / std::fabs(fD) + 3 * EPSF;
             ok = dBs < 0.125 && dBt < 0.125 && std::isfinite(dBs) && std::isfinite(dBt);
+            // a point the reference accepts lies within (dBs, dBt) barycentric units of the triangle
+            ex.box_pad = (float)(4.0 * (dBs + dBt) * (le1 + le2));
             if (ok) {
                 // Each coordinate as a function of the two hit-point coordinates (u, v) other than
                 // the normal's dominant axis k: on the plane x_k = (d0 - n_u x_u - n_v x_v) / n_k.
@@ -584,6 +666,21 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
         }
     }
 
+    c->h_groups = groups;
+    c->scene_bound = R;
+    c->h_centroid_box.assign(6 * groups.size(), 0.f);
+    for (size_t gi = 0; gi < groups.size(); gi++) {
+        float* bx = &c->h_centroid_box[6 * gi];
+        for (int a = 0; a < 3; a++) { bx[a] = FLT_MAX; bx[3 + a] = -FLT_MAX; }
+        for (int k2 = groups[gi].fax[0]; k2 < groups[gi].fax[3]; k2++) {
+            const TriExact& ex = exact[k2];
+            for (int a = 0; a < 3; a++) {
+                float cc = (float)(ex.v1[a] + (ex.e1[a] + ex.e2[a]) * (1.0 / 3.0));
+                bx[a] = std::min(bx[a], cc); bx[3 + a] = std::max(bx[3 + a], cc);
+            }
+        }
+    }
+
     std::vector<DevMaterial> mats(d->n_materials);
     for (int i = 0; i < d->n_materials; i++) std::memcpy(&mats[i], &d->materials[i], sizeof(DevMaterial));
     std::vector<DevLight> lights(d->n_lights);
@@ -660,7 +757,13 @@ int rt_set_option(rt_ctx* c, int option, int64_t value) {
             if (value < 1) return fail(RT_ERR_ARG, "rt_set_option: pass pixels must be positive");
             c->pass_pixels = value;
             return 0;
-        case RT_OPT_USE_BVH: return value ? fail(RT_ERR_STATE, "rt_set_option: no BVH has been built") : 0;
+        case RT_OPT_USE_BVH:
+            if (value) {
+                int rc = build_bvh(c);
+                if (rc) return rc;
+            }
+            c->use_bvh = value ? 1 : 0;
+            return 0;
         default: return fail(RT_ERR_ARG, "rt_set_option: unknown option");
     }
 }
@@ -712,6 +815,8 @@ int rt_get_stats(rt_ctx* c, rt_stats* out) {
     out->rays_primary = dc.rays_primary; out->rays_reflect = dc.rays_reflect; out->rays_shadow = dc.rays_shadow;
     out->hits = dc.hits; out->closest_tests = dc.closest_tests; out->anyhit_tests = dc.anyhit_tests;
     out->exact_tests = dc.exact_tests;
+    out->bvh_node_tests = dc.bvh_node_tests; out->bvh_leaf_tests = dc.bvh_leaf_tests;
+    out->in_plane_origin_hits = dc.in_plane_origin_hits;
     out->closest_ms = c->ms[0]; out->anyhit_ms = c->ms[1];
     out->closest_launches = c->launches[0]; out->anyhit_launches = c->launches[1];
     out->exact_ms = c->ms[2]; out->exact_launches = c->launches[2];
@@ -745,6 +850,7 @@ void rt_free(rt_ctx* c) {
     c->aux.release(); c->occluded.release(); c->pixel_of_ray.release(); c->lvl_parent.release();
     c->lvl_obj.release(); c->lvl_phong.release(); c->lvl_child.release(); c->counts.release();
     c->ray_flags.release(); c->pairs.release(); c->pair_count.release();
+    c->bvh_nodes.release(); c->bvh_groups.release();
     delete c;
 }
 

@@ -1,0 +1,287 @@
+// Optional LBVH over the regular triangles of each transform group.
+//
+// The hierarchy is one more CONSERVATIVE filter in front of the reference-precision test:
+// traversal never orders or prunes by distance, it collects every triangle whose padded
+// box the ray's half-line can reach, runs the same FP32 triangle filter as the brute-force
+// scan on it, and appends the survivors to the same pair list.  k_exact_pairs / k_brute then
+// decide exactly as in brute-force mode, so the nearest hit (index and distance bits) is the
+// brute-force one.  The one reference behaviour a box hierarchy cannot reproduce is the
+// in-plane-origin case of Triangle::intersection (raytracer.cpp:319-321: a == 0 with a
+// grazing ray "hits" the infinite plane, wherever the triangle is); rt_stats counts those
+// events in brute-force mode so a caller can tell whether a scene has any.
+//
+// Build (GPU): Morton codes of the centroids -> rocPRIM radix sort -> Karras' parallel
+// hierarchy (2012) on (code, index) keys -> bottom-up box refit with one atomic counter per
+// internal node.  Every ray that cannot be traversed safely (stack overflow, origin out of
+// the filter's bounds) is flagged and takes k_brute's full scan instead.
+#pragma once
+
+#include "rt_kernels.h"
+
+#define RT_BVH_BLOCK 256
+#define RT_BVH_STACK 32         // per-lane traversal stack entries (LDS)
+#define RT_BVH_STAGE 16         // per-lane staged candidates (LDS)
+
+struct __attribute__((aligned(16))) BvhNode {
+    float lo[2][3], hi[2][3];   // boxes of the two children
+    int32_t child[2];           // >= 0: internal node (index into the group's node array); < 0: triangle slot -1 - child
+    int32_t pad[2];
+};
+
+struct GroupBvh {
+    const BvhNode* nodes;       // n - 1 internal nodes, root = node 0
+    int32_t n;                  // triangles in the group
+    int32_t first_slot;         // n == 1: the only triangle's slot
+};
+
+// ---- build ----------------------------------------------------------------
+
+__device__ __forceinline__ unsigned int expand_bits10(unsigned int v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+// 30-bit Morton code of each triangle's centroid inside the group's centroid box.
+__global__ void k_bvh_morton(const TriExact* __restrict__ exact, int base, int n, float3 cmin, float3 cscale,
+                             unsigned int* __restrict__ keys, int* __restrict__ vals) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const TriExact& T = exact[base + i];
+    float c[3];
+    for (int k = 0; k < 3; k++) c[k] = (float)(T.v1[k] + (T.e1[k] + T.e2[k]) * (1.0 / 3.0));
+    float q[3] = {(c[0] - cmin.x) * cscale.x, (c[1] - cmin.y) * cscale.y, (c[2] - cmin.z) * cscale.z};
+    unsigned int code = 0;
+    for (int k = 0; k < 3; k++) {
+        float v = fminf(fmaxf(q[k] * 1024.0f, 0.0f), 1023.0f);
+        code |= expand_bits10((unsigned int)v) << (2 - k);
+    }
+    keys[i] = code;
+    vals[i] = i;
+}
+
+// Common-prefix length of sorted keys i and j; equal codes are told apart by their position.
+__device__ __forceinline__ int bvh_delta(const unsigned int* __restrict__ keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    unsigned int a = keys[i], b = keys[j];
+    if (a == b) return 32 + __clz((unsigned int)(i ^ j));
+    return __clz(a ^ b);
+}
+
+// Karras 2012: internal node i of n - 1; leaves are sorted positions 0 .. n-1.
+__global__ void k_bvh_hierarchy(const unsigned int* __restrict__ keys, const int* __restrict__ vals, int n, int base,
+                                BvhNode* __restrict__ nodes, int* __restrict__ parent_of_node,
+                                int* __restrict__ parent_of_leaf) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    int d = (bvh_delta(keys, n, i, i + 1) - bvh_delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    int dmin = bvh_delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (bvh_delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (bvh_delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    int j = i + l * d;
+    int dnode = bvh_delta(keys, n, i, j);
+    int s = 0;
+    for (int t = (l + 1) / 2;; t = (t + 1) / 2) {
+        if (bvh_delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+        if (t <= 1) break;
+    }
+    int gamma = i + s * d + min(d, 0);
+    int lo = min(i, j), hi = max(i, j);
+    // child codes: leaves carry the triangle's slot
+    int left, right;
+    if (lo == gamma) { left = -1 - (base + vals[gamma]); parent_of_leaf[gamma] = 2 * i; }
+    else { left = gamma; parent_of_node[gamma] = 2 * i; }
+    if (hi == gamma + 1) { right = -1 - (base + vals[gamma + 1]); parent_of_leaf[gamma + 1] = 2 * i + 1; }
+    else { right = gamma + 1; parent_of_node[gamma + 1] = 2 * i + 1; }
+    nodes[i].child[0] = left; nodes[i].child[1] = right;
+    nodes[i].pad[0] = nodes[i].pad[1] = 0;
+    if (i == 0) parent_of_node[0] = -1;
+}
+
+__device__ __forceinline__ float round_down(double v) {
+    float f = (float)v;
+    return ((double)f > v) ? nextafterf(f, -INFINITY) : f;
+}
+__device__ __forceinline__ float round_up(double v) {
+    float f = (float)v;
+    return ((double)f < v) ? nextafterf(f, INFINITY) : f;
+}
+
+// Leaf boxes (padded) and the bottom-up union.  The second thread to arrive at a node
+// continues upwards; the boxes it reads were published by the first behind a device-scope fence.
+__global__ void k_bvh_refit(const TriExact* __restrict__ exact, const int* __restrict__ vals, int n, int base,
+                            BvhNode* nodes, const int* __restrict__ parent_of_node, const int* __restrict__ parent_of_leaf,
+                            unsigned int* arrive, float pad_abs) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const TriExact& T = exact[base + vals[k]];
+    float lo[3], hi[3];
+    const float pad = pad_abs + T.box_pad;
+    for (int a = 0; a < 3; a++) {
+        double p0 = T.v1[a], p1 = T.v1[a] + T.e1[a], p2 = T.v1[a] + T.e2[a];
+        lo[a] = round_down(fmin(p0, fmin(p1, p2))) - pad;
+        hi[a] = round_up(fmax(p0, fmax(p1, p2))) + pad;
+    }
+    int link = parent_of_leaf[k];
+    while (link >= 0) {
+        const int node = link >> 1, side = link & 1;
+        for (int a = 0; a < 3; a++) {
+            __hip_atomic_store(&nodes[node].lo[side][a], lo[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&nodes[node].hi[side][a], hi[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __threadfence();
+        if (atomicAdd(&arrive[node], 1u) == 0u) return;     // the sibling subtree is not finished yet
+        __threadfence();
+        for (int a = 0; a < 3; a++) {
+            float olo = __hip_atomic_load(&nodes[node].lo[side ^ 1][a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float ohi = __hip_atomic_load(&nodes[node].hi[side ^ 1][a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lo[a] = fminf(lo[a], olo);
+            hi[a] = fmaxf(hi[a], ohi);
+        }
+        link = parent_of_node[node];
+    }
+}
+
+// ---- traversal --------------------------------------------------------------
+
+struct BvhCounters { unsigned long long node_tests, leaf_tests; };
+
+// The brute-force filter's test for ONE ray and a triangle record fetched per lane.
+__device__ __forceinline__ bool filter_keep1(const float* __restrict__ f, int axis, float px, float py, float pz,
+                                             float vx, float vy, float vz, const float rlo, const float az) {
+    float b = f[0] * vx;
+    b = __builtin_fmaf(f[1], vy, b);
+    b = __builtin_fmaf(f[2], vz, b);
+    float a = __builtin_fmaf(-f[0], px, f[3]);
+    a = __builtin_fmaf(-f[1], py, a);
+    a = __builtin_fmaf(-f[2], pz, a);
+    const float r = a * __builtin_amdgcn_rcpf(b);
+    const float pu = axis == 0 ? py : (axis == 1 ? pz : px), pv = axis == 0 ? pz : (axis == 1 ? px : py);
+    const float vu = axis == 0 ? vy : (axis == 1 ? vz : vx), vv = axis == 0 ? vz : (axis == 1 ? vx : vy);
+    const float hu = __builtin_fmaf(r, vu, pu), hv = __builtin_fmaf(r, vv, pv);
+    const float s = __builtin_fmaf(f[4], hu, __builtin_fmaf(f[5], hv, f[6]));
+    const float t = __builtin_fmaf(f[7], hu, __builtin_fmaf(f[8], hv, f[9]));
+    const float u = __builtin_fmaf(f[10], hu, __builtin_fmaf(f[11], hv, f[12]));
+    const float m = __builtin_fminf(__builtin_fminf(s, t), u);
+    const bool reject = (m < 0.0f) | (r < rlo);
+    return (!reject) | (fabsf(a) <= az);
+}
+
+// Can the half-line P + tV, t >= 0, reach the (already padded) box?  NaNs (0 * inf on a slab
+// boundary) drop out of min/max, which only widens the interval.
+__device__ __forceinline__ bool ray_reaches_box(const float* lo, const float* hi, float px, float py, float pz,
+                                                float ix, float iy, float iz) {
+    const float x0 = (lo[0] - px) * ix, x1 = (hi[0] - px) * ix;
+    const float y0 = (lo[1] - py) * iy, y1 = (hi[1] - py) * iy;
+    const float z0 = (lo[2] - pz) * iz, z1 = (hi[2] - pz) * iz;
+    float tnear = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+    float tfar = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+    tnear -= fabsf(tnear) * 1e-5f;
+    tfar += fabsf(tfar) * 1e-5f;
+    return !(tnear > tfar) && !(tfar < 0.0f);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(RT_BVH_BLOCK)
+k_bvh_trace(const DevScene* __restrict__ sc, const GroupBvh* __restrict__ bvh, const float* __restrict__ filt,
+            TraceArgs A, BvhCounters* counters) {
+    __shared__ int stack[RT_BVH_STACK * RT_BVH_BLOCK];
+    __shared__ unsigned int stage[RT_BVH_STAGE * RT_BVH_BLOCK];
+    int* my_stack = stack + threadIdx.x;                 // entry k at my_stack[k * RT_BVH_BLOCK]
+    unsigned int* my_stage = stage + threadIdx.x;
+    const int lane = threadIdx.x & (RT_WAVE - 1);
+    const unsigned int n_lights = sc->n_lights;
+    const unsigned int n_hits = __builtin_amdgcn_readfirstlane(*A.n_items);
+    const unsigned int n_rays = (MODE == 0) ? n_hits : n_hits * n_lights;
+    const FilterParams fp = (MODE == 0) ? sc->fp_closest : sc->fp_shadow;
+    const float ob = sc->origin_bound, vb = sc->dir_len2_bound;
+    const int n_groups = sc->n_groups;
+    unsigned long long n_node = 0, n_leaf = 0;
+
+    const unsigned int stride = gridDim.x * blockDim.x;
+    const unsigned int n_round = (n_rays + stride - 1) / stride * stride;
+    for (unsigned int ray = blockIdx.x * blockDim.x + threadIdx.x; ray < n_round; ray += stride) {
+        const bool valid = ray < n_rays;
+        int n_staged = 0;
+        bool bail = false;                              // this ray takes the full reference-precision scan instead
+        d3 wpos = mk3(0, 0, 0), wvec = mk3(0, 0, 1);
+        int source = -1;
+        if (valid) load_world_ray<MODE>(A, sc, ray, n_lights, &wpos, &wvec, &source);
+        for (int g = 0; g < n_groups && valid && !bail; g++) {
+            const Group& G = sc->groups[g];
+            const GroupBvh B = bvh[g];
+            if (B.n <= 0) continue;
+            d3 pos = wpos, vec = wvec;
+            if (MODE == 0) to_object_space(sc->xforms + 48 * (size_t)G.xf, G.identity, &pos, &vec);
+            const float px = (float)pos.x, py = (float)pos.y, pz = (float)pos.z;
+            const float vx = (float)vec.x, vy = (float)vec.y, vz = (float)vec.z;
+            const bool trusted = fabsf(px) <= ob && fabsf(py) <= ob && fabsf(pz) <= ob && (vx * vx + vy * vy + vz * vz) <= vb;
+            if (!trusted) { bail = true; break; }
+            const float ix = 1.0f / vx, iy = 1.0f / vy, iz = 1.0f / vz;
+            const int fax1 = G.fax[1], fax2 = G.fax[2];
+            int sp = 0;
+            int cur = (B.n == 1) ? (-1 - B.first_slot) : 0;
+            for (;;) {
+                if (cur < 0) {
+                    // leaf: the FP32 triangle filter, then the pair list
+                    const int slot = -1 - cur;
+                    const int axis = slot >= fax2 ? 2 : (slot >= fax1 ? 1 : 0);
+                    n_leaf++;
+                    if (filter_keep1(filt + 16 * (size_t)slot, axis, px, py, pz, vx, vy, vz, fp.r_lo, fp.a_zero)) {
+                        if (n_staged < RT_BVH_STAGE) { my_stage[n_staged * RT_BVH_BLOCK] = (unsigned int)slot; n_staged++; }
+                        else bail = true;                // staging full: let k_brute handle this ray
+                    }
+                    if (sp == 0 || bail) break;
+                    cur = my_stack[(--sp) * RT_BVH_BLOCK];
+                    continue;
+                }
+                const BvhNode& N = B.nodes[cur];
+                n_node += 2;
+                const bool h0 = ray_reaches_box(N.lo[0], N.hi[0], px, py, pz, ix, iy, iz);
+                const bool h1 = ray_reaches_box(N.lo[1], N.hi[1], px, py, pz, ix, iy, iz);
+                if (h0 && h1) {
+                    if (sp < RT_BVH_STACK) my_stack[(sp++) * RT_BVH_BLOCK] = N.child[1];
+                    else { bail = true; break; }
+                    cur = N.child[0];
+                } else if (h0) {
+                    cur = N.child[0];
+                } else if (h1) {
+                    cur = N.child[1];
+                } else {
+                    if (sp == 0) break;
+                    cur = my_stack[(--sp) * RT_BVH_BLOCK];
+                }
+            }
+        }
+        if (valid && bail) { A.ray_flags[ray] = 1; n_staged = 0; }
+        // append the staged candidates: one atomic per wave
+        int incl = n_staged;
+        for (int off = 1; off < RT_WAVE; off <<= 1) {
+            int up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        const int total = __shfl(incl, RT_WAVE - 1);
+        if (total > 0) {
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(A.pair_count, (unsigned int)total);
+            base = __shfl(base, 0);
+            if (base + (unsigned int)total > A.pair_cap || base + (unsigned int)total < base) {
+                if (valid && n_staged > 0) A.ray_flags[ray] = 1;
+            } else {
+                unsigned long long* out = A.pairs + base + (unsigned int)(incl - n_staged);
+                for (int k = 0; k < n_staged; k++)
+                    out[k] = ((unsigned long long)ray << 32) | my_stage[k * RT_BVH_BLOCK];
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { n_node += __shfl_xor(n_node, off); n_leaf += __shfl_xor(n_leaf, off); }
+    if (lane == 0) {
+        if (n_node) atomicAdd(&counters->node_tests, n_node);
+        if (n_leaf) atomicAdd(&counters->leaf_tests, n_leaf);
+    }
+}

@@ -26,7 +26,8 @@ struct __attribute__((aligned(16))) TriExact {
     float uu, uv, vv, D;   // raytracer.cpp:334-340, each rounded as the reference does
     int32_t obj;       // index in Scene::objects
     int32_t grp;       // index of the transform group
-    int32_t pad[2];
+    float box_pad;     // how far outside the triangle the reference's own rounding can accept a point
+    int32_t pad;
 };
 
 struct __attribute__((aligned(16))) SphereRec {
@@ -125,14 +126,19 @@ __device__ __forceinline__ d3 xf_dir(const double* m, d3 v) {
 }
 
 // Triangle::intersection (raytracer.cpp:312-357) on a precomputed record.
-__device__ __forceinline__ float tri_intersect_exact(const TriExact& T, d3 pos, d3 vec, float eps) {
+__device__ __forceinline__ float tri_intersect_exact(const TriExact& T, d3 pos, d3 vec, float eps,
+                                                     bool* in_plane_origin = nullptr) {
     d3 v1 = ld3(T.v1), e1 = ld3(T.e1), e2 = ld3(T.e2), nrm = ld3(T.n);
     d3 w0 = sub3(pos, v1);
     float a = (float)(-dot3(nrm, w0));
     float b = (float)dot3(nrm, vec);
     float r = a / b;
     if (fabsf(b) < eps) {
-        return (a == 0.0f) ? r : RT_MISS_T;
+        if (a == 0.0f) {                 // origin in the plane, ray grazing it: "hit" at r = 0/b (raytracer.cpp:320)
+            if (in_plane_origin) *in_plane_origin = true;
+            return r;
+        }
+        return RT_MISS_T;
     }
     if (r < 0.0f) return RT_MISS_T;
     d3 isect = add3(pos, scl3(vec, (double)r));

@@ -55,6 +55,8 @@ struct PassDesc {               // rows traced by one pass, see rt_render_tiles
 struct DevCounters {
     unsigned long long rays_primary, rays_reflect, rays_shadow, hits;
     unsigned long long closest_tests, anyhit_tests, exact_tests;
+    unsigned long long bvh_node_tests, bvh_leaf_tests;   // written through BvhCounters (same layout)
+    unsigned long long in_plane_origin_hits;
 };
 
 // ---------------------------------------------------------------------------
@@ -443,7 +445,9 @@ k_exact_pairs(const DevScene* __restrict__ sc, const TriExact* __restrict__ exac
         int source;
         load_world_ray<MODE>(A, sc, ray, n_lights, &pos, &vec, &source);
         to_object_space(X, ident, &pos, &vec);
-        const float t = tri_intersect_exact(T, pos, vec, eps);
+        bool q7 = false;
+        const float t = tri_intersect_exact(T, pos, vec, eps, &q7);
+        if (q7) atomicAdd(&A.counters->in_plane_origin_hits, 1ull);
         publish_result<MODE>(A, ray, n_lights, t, T.obj, pos, vec, X, ident, source);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&A.counters->exact_tests, (unsigned long long)n);
