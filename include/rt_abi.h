@@ -105,6 +105,7 @@ typedef struct rt_stats {
     uint64_t bvh_leaf_tests; /* RT_OPT_USE_BVH: triangles reached at the leaves */
     uint64_t in_plane_origin_hits; /* listed pairs that took the a == 0 branch of Triangle::intersection
                                       (raytracer.cpp:319-321), the one case a box hierarchy cannot find */
+    uint64_t flagged_rays;   /* rays that bypassed the filter / hierarchy and were scanned in full */
     double closest_ms;       /* RT_OPT_PROFILE: summed duration of the nearest-hit filter kernel launches */
     double anyhit_ms;        /* RT_OPT_PROFILE: summed duration of the shadow filter kernel launches */
     double exact_ms;         /* RT_OPT_PROFILE: summed duration of the reference-precision kernels */

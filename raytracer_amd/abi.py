@@ -48,7 +48,8 @@ class RtStats(C.Structure):
         ("rays_primary", C.c_uint64), ("rays_reflect", C.c_uint64), ("rays_shadow", C.c_uint64),
         ("hits", C.c_uint64), ("closest_tests", C.c_uint64), ("anyhit_tests", C.c_uint64),
         ("exact_tests", C.c_uint64), ("bvh_node_tests", C.c_uint64), ("bvh_leaf_tests", C.c_uint64),
-        ("in_plane_origin_hits", C.c_uint64), ("closest_ms", C.c_double), ("anyhit_ms", C.c_double),
+        ("in_plane_origin_hits", C.c_uint64), ("flagged_rays", C.c_uint64),
+        ("closest_ms", C.c_double), ("anyhit_ms", C.c_double),
         ("exact_ms", C.c_double),
         ("closest_launches", C.c_uint32), ("anyhit_launches", C.c_uint32), ("exact_launches", C.c_uint32),
         ("n_triangles", C.c_int32), ("n_spheres", C.c_int32), ("n_groups", C.c_int32),

@@ -816,7 +816,7 @@ int rt_get_stats(rt_ctx* c, rt_stats* out) {
     out->hits = dc.hits; out->closest_tests = dc.closest_tests; out->anyhit_tests = dc.anyhit_tests;
     out->exact_tests = dc.exact_tests;
     out->bvh_node_tests = dc.bvh_node_tests; out->bvh_leaf_tests = dc.bvh_leaf_tests;
-    out->in_plane_origin_hits = dc.in_plane_origin_hits;
+    out->in_plane_origin_hits = dc.in_plane_origin_hits; out->flagged_rays = dc.flagged_rays;
     out->closest_ms = c->ms[0]; out->anyhit_ms = c->ms[1];
     out->closest_launches = c->launches[0]; out->anyhit_launches = c->launches[1];
     out->exact_ms = c->ms[2]; out->exact_launches = c->launches[2];

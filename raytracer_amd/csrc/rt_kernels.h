@@ -57,6 +57,7 @@ struct DevCounters {
     unsigned long long closest_tests, anyhit_tests, exact_tests;
     unsigned long long bvh_node_tests, bvh_leaf_tests;   // written through BvhCounters (same layout)
     unsigned long long in_plane_origin_hits;
+    unsigned long long flagged_rays;                     // rays that took k_brute's full scan (per launch and part 0 only)
 };
 
 // ---------------------------------------------------------------------------
@@ -486,6 +487,10 @@ k_brute(const DevScene* __restrict__ sc, const TriExact* __restrict__ exact, Tra
         const bool valid = ray < n_rays;
         const bool scan = valid && (A.scan_all || A.ray_flags[ray] != 0);
         const bool any_scan = __any(scan);
+        if (part == 0 && !A.scan_all && any_scan) {
+            const unsigned long long m = __ballot(scan);
+            if (lane == 0) atomicAdd(&A.counters->flagged_rays, (unsigned long long)__popcll(m));
+        }
         if (!any_scan && (part != 0 || NS + NI == 0)) continue;
         d3 wpos = mk3(0, 0, 0), wvec = mk3(0, 0, 1);
         int source = -1;
@@ -527,10 +532,19 @@ k_brute(const DevScene* __restrict__ sc, const TriExact* __restrict__ exact, Tra
                 const int per_part = __builtin_amdgcn_readfirstlane((glen + split - 1) / split);
                 const int pbeg = fbeg + part * per_part;
                 const int pend = min(fend, pbeg + per_part);
-                if (scan) {
-                    for (int j = pbeg; j < pend; j++) {
-                        const float t = tri_intersect_exact(exact[j], pos, vec, eps);
-                        publish_result<MODE>(A, ray, n_lights, t, exact[j].obj, pos, vec, X, ident, source);
+                // The whole wave works on one flagged ray at a time, 64 triangles per step: a
+                // handful of flagged rays must not turn into a long single-lane tail.
+                unsigned long long todo = __ballot(scan);
+                while (todo) {
+                    const int src = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    const d3 bpos = mk3(__shfl(pos.x, src), __shfl(pos.y, src), __shfl(pos.z, src));
+                    const d3 bvec = mk3(__shfl(vec.x, src), __shfl(vec.y, src), __shfl(vec.z, src));
+                    const unsigned int bray = (unsigned int)__shfl((int)ray, src);
+                    const int bsource = __shfl(source, src);
+                    for (int j = pbeg + lane; j < pend; j += RT_WAVE) {
+                        const float t = tri_intersect_exact(exact[j], bpos, bvec, eps);
+                        publish_result<MODE>(A, bray, n_lights, t, exact[j].obj, bpos, bvec, X, ident, bsource);
                         n_exact++;
                     }
                 }
