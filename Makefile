@@ -9,10 +9,11 @@ HOST_SRC := $(PKG)/host/scene_loader.cpp $(PKG)/host/png_writer.cpp
 HIP_SRC := $(wildcard $(PKG)/csrc/*.hip)
 HIP_HDR := $(wildcard $(PKG)/csrc/*.h) include/rt_abi.h
 
-all: host hip oracle
+all: host hip cli oracle
 
 host: $(PKG)/librt_host.so
 hip: $(PKG)/libraytracer_amd.so
+cli: $(PKG)/rt_render
 
 $(PKG)/librt_host.so: $(HOST_SRC) include/rt_host.h include/rt_abi.h
 	$(CXX) -O2 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -Iinclude -o $@ $(HOST_SRC) -lz
@@ -23,10 +24,14 @@ $(PKG)/libraytracer_amd.so: $(HIP_SRC) $(HIP_HDR)
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -Iinclude -I$(PKG)/csrc \
 	  -o $@ $(HIP_SRC)
 
+# The host driver (the reference's main): links both libraries, found at run time next to itself.
+$(PKG)/rt_render: $(PKG)/host/rt_cli.cpp $(PKG)/librt_host.so $(PKG)/libraytracer_amd.so include/rt_abi.h include/rt_host.h
+	$(CXX) -O2 -std=c++17 -Iinclude -o $@ $(PKG)/host/rt_cli.cpp -L$(PKG) -lrt_host -lraytracer_amd -Wl,-rpath,'$$ORIGIN' -Wl,-rpath-link,/opt/rocm/lib
+
 oracle:
 	$(MAKE) -C oracle all
 
 clean:
-	rm -f $(PKG)/*.so oracle/*.so
+	rm -f $(PKG)/*.so $(PKG)/rt_render oracle/*.so
 
-.PHONY: all host hip oracle clean
+.PHONY: all host hip cli oracle clean

@@ -158,3 +158,22 @@ def test_edge_cases():
     with pytest.raises(DeviceError):
         r.set_option(99, 1)
     r.close()
+
+
+def test_cli_driver_writes_the_reference_image(tmp_path):
+    """The C++ host driver (the reference's main) end to end: scene file -> PNG."""
+    import subprocess
+    exe = os.path.join(ROOT, "raytracer_amd", "rt_render")
+    assert os.path.exists(exe), "run `make cli`"
+    out = tmp_path / "out.png"
+    gold = os.path.join(ROOT, "tests", "golden", "ref_renders", "mixed_xf_160x120_d4.png")
+    res = subprocess.run([exe, os.path.join(ROOT, "scenes", "mixed_xf.scene"), str(out), "-w", "160", "-h", "120",
+                          "-depth", "4", "-stats"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    assert_parity(oracle_api.load_png(str(out)), oracle_api.load_png(gold), max_diff_pixels=2)
+    # defaults are the reference's: 1000 x 1000, depth 6, eps 0.05 (raytracer.cpp:849-851, 477)
+    out2 = tmp_path / "d.png"
+    res = subprocess.run([exe, os.path.join(ROOT, "scenes", "inputs", "input-03"), str(out2)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    want = oracle_api.load_png(os.path.join(ROOT, "tests", "golden", "images", "image-03.png"))
+    assert_parity(oracle_api.load_png(str(out2)), want, max_diff_pixels=3)
