@@ -19,8 +19,8 @@
 #include "rt_kernels.h"
 
 #define RT_BVH_BLOCK 256
-#define RT_BVH_STACK 32         // per-lane traversal stack entries (LDS)
-#define RT_BVH_STAGE 16         // per-lane staged candidates (LDS)
+#define RT_BVH_STACK 40         // per-lane traversal stack entries (LDS)
+#define RT_BVH_STAGE 8          // per-lane staged candidates (LDS)
 
 struct __attribute__((aligned(16))) BvhNode {
     float lo[2][3], hi[2][3];   // boxes of the two children
@@ -233,8 +233,17 @@ k_bvh_trace(const DevScene* __restrict__ sc, const GroupBvh* __restrict__ bvh, c
                     const int axis = slot >= fax2 ? 2 : (slot >= fax1 ? 1 : 0);
                     n_leaf++;
                     if (filter_keep1(filt + 16 * (size_t)slot, axis, px, py, pz, vx, vy, vz, fp.r_lo, fp.a_zero)) {
-                        if (n_staged < RT_BVH_STAGE) { my_stage[n_staged * RT_BVH_BLOCK] = (unsigned int)slot; n_staged++; }
-                        else bail = true;                // staging full: let k_brute handle this ray
+                        if (n_staged == RT_BVH_STAGE) {
+                            // staging full: this lane appends its entries on its own (rare), then goes on
+                            const unsigned int base = atomicAdd(A.pair_count, (unsigned int)RT_BVH_STAGE);
+                            if (base + RT_BVH_STAGE > A.pair_cap || base + RT_BVH_STAGE < base) bail = true;
+                            else
+                                for (int k = 0; k < RT_BVH_STAGE; k++)
+                                    A.pairs[base + k] = ((unsigned long long)ray << 32) | my_stage[k * RT_BVH_BLOCK];
+                            n_staged = 0;
+                        }
+                        my_stage[n_staged * RT_BVH_BLOCK] = (unsigned int)slot;
+                        n_staged++;
                     }
                     if (sp == 0 || bail) break;
                     cur = my_stack[(--sp) * RT_BVH_BLOCK];
