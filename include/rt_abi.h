@@ -89,7 +89,12 @@ typedef enum rt_option {
     RT_OPT_PROFILE = 2,      /* 1: bracket every trace-kernel launch with HIP events; the sums
                                 appear in rt_stats */
     RT_OPT_PASS_PIXELS = 3,  /* pixels traced per internal pass (bounds the workspace) */
-    RT_OPT_USE_BVH = 4       /* 1: build (once) and use the LBVH in place of the brute-force triangle scan */
+    RT_OPT_USE_BVH = 4,      /* 1: build (once) and use the LBVH in place of the brute-force triangle scan */
+    RT_OPT_FILTER_FORM = 5   /* form of the FP32 candidate filter: 0 = chosen from the scene when it was
+                                uploaded (default), 1 = static worst-case margins (cheapest test), 2 = per-test
+                                margins (two more instructions per test; for meshes of triangles that are
+                                tiny against the scene, or with many triangles in one plane).  Frames are
+                                identical in every form; blocks until queued work has finished */
 } rt_option;
 
 /* Counters since rt_upload_scene or the last rt_reset_stats. */
@@ -111,7 +116,7 @@ typedef struct rt_stats {
     double exact_ms;         /* RT_OPT_PROFILE: summed duration of the reference-precision kernels */
     uint32_t closest_launches, anyhit_launches, exact_launches;
     int32_t n_triangles, n_spheres, n_groups, n_irregular;
-    int32_t reserved;
+    int32_t filter_form;     /* 1 = static margins, 2 = per-test margins (see RT_OPT_FILTER_FORM) */
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 RT_OK, RT_ERR_ARG, RT_ERR_DEVICE, RT_ERR_RANGE, RT_ERR_STATE = 0, -1, -2, -3, -4
-RT_OPT_EXACT_ONLY, RT_OPT_PROFILE, RT_OPT_PASS_PIXELS, RT_OPT_USE_BVH = 1, 2, 3, 4
+RT_OPT_EXACT_ONLY, RT_OPT_PROFILE, RT_OPT_PASS_PIXELS, RT_OPT_USE_BVH, RT_OPT_FILTER_FORM = 1, 2, 3, 4, 5
 
 
 class RtMaterial(C.Structure):
@@ -53,7 +53,7 @@ class RtStats(C.Structure):
         ("exact_ms", C.c_double),
         ("closest_launches", C.c_uint32), ("anyhit_launches", C.c_uint32), ("exact_launches", C.c_uint32),
         ("n_triangles", C.c_int32), ("n_spheres", C.c_int32), ("n_groups", C.c_int32),
-        ("n_irregular", C.c_int32), ("reserved", C.c_int32),
+        ("n_irregular", C.c_int32), ("filter_form", C.c_int32),
     ]
 
     def as_dict(self):

@@ -3,6 +3,7 @@
 // rt_kernels.h together, download and statistics.
 #include "rt_abi.h"
 #include <cstring>
+#include <unordered_map>
 #include <string.h>
 
 #include "rt_kernels.h"
@@ -83,6 +84,16 @@ template <class T> struct DevBuf {
 
 }  // namespace
 
+// One triangle as the host keeps it: the reference-precision record and the filter record in
+// both forms (static worst-case margins / per-test margins), see filter_keep2.
+struct HostTri {
+    TriExact ex;
+    float f_static[16], f_robust[16];
+    bool ok_static, ok_robust;
+    float margin_static;      // the u plane's static margin in barycentric units
+    int xf, axis;
+};
+
 struct rt_ctx {
     int device = 0;
     int n_cu = 0;
@@ -115,8 +126,16 @@ struct rt_ctx {
     DevBuf<uint32_t> counts;       // [levels + 1]
     DevBuf<uint8_t> ray_flags;     // [cap * max(1, n_lights)]
     DevBuf<unsigned long long> pairs;
-    DevBuf<unsigned int> pair_count;
+    DevBuf<unsigned long long> pair_count;
     size_t pair_cap = 0;
+
+    // host copies kept so that the filter form can be switched after the upload
+    std::vector<HostTri> h_tris;          // in Scene::objects order (triangles only)
+    std::vector<GroupFilter> h_q0, h_q1;  // per transform: nearest-hit / shadow thresholds
+    std::vector<int32_t> h_slot;          // per object: slot of its record (spheres: fixed; triangles: per form)
+    std::vector<int32_t> h_xf_ident;
+    int auto_robust = 0;                  // the form chosen from the scene's own numbers
+    int robust = 0;                       // the form installed now
 
     // optional LBVH (RT_OPT_USE_BVH)
     int use_bvh = 0;
@@ -238,9 +257,9 @@ template <int MODE>
 int launch_trace(rt_ctx* c, TraceArgs A, hipStream_t st) {
     const DevScene* dsc = c->d_scene.p;
     A.ray_flags = c->ray_flags.p; A.pairs = c->pairs.p; A.pair_count = c->pair_count.p;
-    A.task_counter = c->pair_count.p + 1;
+    A.task_counter = (unsigned int*)(c->pair_count.p + 1);
     A.pair_cap = (unsigned int)c->pair_cap; A.counters = c->counters.p; A.scan_all = c->force_exact;
-    HIP_TRY(hipMemsetAsync(c->pair_count.p, 0, 2 * sizeof(unsigned int), st));
+    HIP_TRY(hipMemsetAsync(c->pair_count.p, 0, 2 * sizeof(unsigned long long), st));
     HIP_TRY(hipMemsetAsync(c->ray_flags.p, 0, c->ray_flags.n, st));
     if (!c->force_exact && c->hs.n_regular > 0) {
         Timed t(c, st, MODE);
@@ -249,8 +268,12 @@ int launch_trace(rt_ctx* c, TraceArgs A, hipStream_t st) {
             hipLaunchKernelGGL(k_bvh_trace<MODE>, dim3(c->aux_grid), dim3(RT_BVH_BLOCK), 0, st, dsc,
                                (const GroupBvh*)c->bvh_groups.p, (const float*)c->tri_filt.p, A, bc);
         } else {
-            hipLaunchKernelGGL((k_filter<MODE, RT_RPL>), dim3(c->filter_grid[MODE]), dim3(RT_BLOCK), 0, st, dsc,
-                               (const v16f*)c->tri_filt.p, A);
+            if (c->robust)
+                hipLaunchKernelGGL((k_filter<MODE, RT_RPL, true>), dim3(c->filter_grid[MODE]), dim3(RT_BLOCK), 0, st, dsc,
+                                   (const v16f*)c->tri_filt.p, A);
+            else
+                hipLaunchKernelGGL((k_filter<MODE, RT_RPL, false>), dim3(c->filter_grid[MODE]), dim3(RT_BLOCK), 0, st, dsc,
+                                   (const v16f*)c->tri_filt.p, A);
         }
         HIP_TRY(hipGetLastError());
         t.stop();
@@ -407,11 +430,98 @@ int render_rows(rt_ctx* c, int y_start, int tile_rows, int stride_rows, int n_ti
     return 0;
 }
 
+// Orders the triangles for the chosen form of the filter (regular ones by transform group and
+// dominant axis, then the irregular ones), builds the groups, and uploads the triangle records,
+// the groups and the scene header.  Called by rt_upload_scene and by RT_OPT_FILTER_FORM.
+int install_filter(rt_ctx* c, int robust) {
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());          // no launch may still read the records replaced here
+    const std::vector<HostTri>& tris = c->h_tris;
+    auto regular = [&](const HostTri& t) { return robust ? t.ok_robust : t.ok_static; };
+    std::vector<int> order_reg, order_irr;
+    for (int k = 0; k < (int)tris.size(); k++) (regular(tris[k]) ? order_reg : order_irr).push_back(k);
+    auto by_xf = [&](int a, int b) { return tris[a].xf < tris[b].xf; };
+    auto by_xf_axis = [&](int a, int b) {
+        return tris[a].xf != tris[b].xf ? tris[a].xf < tris[b].xf : tris[a].axis < tris[b].axis;
+    };
+    std::stable_sort(order_reg.begin(), order_reg.end(), by_xf_axis);
+    std::stable_sort(order_irr.begin(), order_irr.end(), by_xf);
+    const int NR = (int)order_reg.size(), NI = (int)order_irr.size();
+    std::vector<v16f> filt((size_t)NR + 1);          // + one readable padding record
+    std::memset(filt.data(), 0, filt.size() * sizeof(v16f));
+    std::vector<TriExact> exact((size_t)NR + NI);
+    std::vector<int32_t>& slot = c->h_slot;
+    for (int k = 0; k < NR; k++) {
+        const HostTri& t = tris[order_reg[k]];
+        const float* f = robust ? t.f_robust : t.f_static;
+        for (int j = 0; j < 16; j++) filt[k][j] = f[j];
+        exact[k] = t.ex;
+        slot[t.ex.obj] = k;
+    }
+    for (int k = 0; k < NI; k++) {
+        const HostTri& t = tris[order_irr[k]];
+        exact[(size_t)NR + k] = t.ex;
+        slot[t.ex.obj] = NR + k;
+    }
+    std::vector<Group> groups;
+    {
+        int r = 0, q = 0;
+        while (r < NR || q < NI) {
+            int xr = r < NR ? tris[order_reg[r]].xf : INT32_MAX;
+            int xq = q < NI ? tris[order_irr[q]].xf : INT32_MAX;
+            int x = std::min(xr, xq);
+            Group G{};
+            G.xf = x; G.identity = c->h_xf_ident[x];
+            G.q[0] = c->h_q0[x]; G.q[1] = c->h_q1[x];
+            for (int a = 0; a < 3; a++) {
+                G.fax[a] = r;
+                while (r < NR && tris[order_reg[r]].xf == x && tris[order_reg[r]].axis == a) r++;
+            }
+            G.fax[3] = r;
+            G.ibeg = NR + q;
+            while (q < NI && tris[order_irr[q]].xf == x) q++;
+            G.iend = NR + q;
+            for (int k2 = G.fax[0]; k2 < G.fax[3]; k2++) exact[k2].grp = (int32_t)groups.size();
+            for (int k2 = G.ibeg; k2 < G.iend; k2++) exact[k2].grp = (int32_t)groups.size();
+            groups.push_back(G);
+        }
+    }
+
+    c->h_groups = groups;
+    c->h_centroid_box.assign(6 * groups.size(), 0.f);
+    for (size_t gi = 0; gi < groups.size(); gi++) {
+        float* bx = &c->h_centroid_box[6 * gi];
+        for (int a = 0; a < 3; a++) { bx[a] = FLT_MAX; bx[3 + a] = -FLT_MAX; }
+        for (int k2 = groups[gi].fax[0]; k2 < groups[gi].fax[3]; k2++) {
+            const TriExact& ex = exact[k2];
+            for (int a = 0; a < 3; a++) {
+                float cc = (float)(ex.v1[a] + (ex.e1[a] + ex.e2[a]) * (1.0 / 3.0));
+                bx[a] = std::min(bx[a], cc); bx[3 + a] = std::max(bx[3 + a], cc);
+            }
+        }
+    }
+    // a hierarchy built over the previous order is void
+    c->bvh_built = false;
+    c->bvh_nodes.release(); c->bvh_groups.release();
+
+    HIP_TRY(c->tri_filt.upload(filt)); HIP_TRY(c->tri_exact.upload(exact));
+    HIP_TRY(c->groups.upload(groups)); HIP_TRY(c->obj_slot.upload(slot));
+    DevScene& s = c->hs;
+    s.tri_filt = c->tri_filt.p; s.tri_exact = c->tri_exact.p; s.groups = c->groups.p; s.obj_slot = c->obj_slot.p;
+    s.n_regular = NR; s.n_irregular = NI; s.n_groups = (int)groups.size();
+    s.robust_filter = robust ? 1 : 0;
+    std::vector<DevScene> one(1, s);
+    HIP_TRY(c->d_scene.upload(one));
+    c->robust = robust ? 1 : 0;
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
 
 const char* rt_last_error(void) { return g_err.c_str(); }
+
 
 int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
     if (!out || !d) return fail(RT_ERR_ARG, "rt_upload_scene: null argument");
@@ -464,7 +574,7 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
     // ---- world bounds: every point a ray can start from ----
     Box world;
     world.add({d->cam_eye[0], d->cam_eye[1], d->cam_eye[2]});
-    double obj_extent = 0.0;   // largest |coordinate| of object-space geometry
+    std::vector<double> xf_extent(std::max(NX, 1), 0.0);   // largest |coordinate| of a transform's object-space vertices
     for (int i = 0; i < N; i++) {
         const double* g = d->obj_geom + 9 * (size_t)i;
         const double* M = &xf[48 * (size_t)d->obj_transform[i]];
@@ -472,7 +582,8 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
             for (int k = 0; k < 3; k++) {
                 Vec v{g[3 * k], g[3 * k + 1], g[3 * k + 2]};
                 world.add(affine_point(M, v));
-                obj_extent = std::max(obj_extent, max_abs(v));
+                double& ext = xf_extent[d->obj_transform[i]];
+                ext = std::max(ext, max_abs(v));
             }
         } else {
             double r = std::fabs(g[3]);
@@ -482,60 +593,77 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
             }
         }
     }
-    double bound = obj_extent;
-    for (int k = 0; k < 8; k++) {
-        Vec w = world.corner(k);
-        bound = std::max(bound, max_abs(w));
-        for (int t = 0; t < NX; t++)
-            if (!xf_ident[t]) bound = std::max(bound, max_abs(affine_point(&xf[48 * (size_t)t + 16], w)));
-    }
-    if (!(bound < 1e30)) bound = 1e30;
-    const double origin_bound = bound * (1.0 + 1e-3) + 1e-3;
-    const double R = std::sqrt(3.0) * origin_bound;
 
-    // ---- direction bound: camera rays are unnormalised, later rays unit length in world space ----
-    double vmax = 1.0;
+    // ---- per transform and kind of query: the magnitudes the filter's operands can have ----
+    // Nearest-hit rays reach a group in its object space (raytracer.cpp:251-259): origins are the
+    // world box under M^-1, camera directions are unnormalised, later directions have unit
+    // length in world space.  Shadow rays stay in world space and meet the untransformed
+    // vertices (raytracer.cpp:553); their directions are normalised (raytracer.cpp:108-119).
+    auto clamp_big = [](double x, double cap) { return x < cap ? x : cap; };   // NaN -> cap
+    auto widen = [](double x) { return x * (1.0 + 1e-3) + 1e-3; };
+    Vec cam_dir[4];
+    double cam_len = 1.0;
     {
         Vec eye{d->cam_eye[0], d->cam_eye[1], d->cam_eye[2]};
         const double* corners[4] = {d->cam_ll, d->cam_lr, d->cam_ul, d->cam_ur};
         for (int k = 0; k < 4; k++) {
-            Vec dir = vsub({corners[k][0], corners[k][1], corners[k][2]}, eye);
-            vmax = std::max(vmax, vlen(dir));
-            for (int t = 0; t < NX; t++)
-                if (!xf_ident[t]) vmax = std::max(vmax, vlen(linear_dir(&xf[48 * (size_t)t + 16], dir)));
+            cam_dir[k] = vsub({corners[k][0], corners[k][1], corners[k][2]}, eye);
+            cam_len = std::max(cam_len, vlen(cam_dir[k]));
         }
-        for (int t = 0; t < NX; t++) {
-            if (xf_ident[t]) continue;
+    }
+    double world_ob = 0.0;
+    for (int k = 0; k < 8; k++) world_ob = std::max(world_ob, max_abs(world.corner(k)));
+    world_ob = widen(clamp_big(world_ob, 1e30));
+    struct Mag { double ob, vm, R; };
+    std::vector<Mag> mag0(std::max(NX, 1)), mag1(std::max(NX, 1));
+    double R_max = std::sqrt(3.0) * world_ob;
+    for (int t = 0; t < NX; t++) {
+        double ob = world_ob, vm = cam_len;
+        if (!xf_ident[t]) {
             const double* I = &xf[48 * (size_t)t + 16];
+            ob = 0.0;
+            for (int k = 0; k < 8; k++) ob = std::max(ob, max_abs(affine_point(I, world.corner(k))));
+            ob = widen(clamp_big(ob, 1e30));
             double fro = 0;
             for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) fro += I[4 * r + cc] * I[4 * r + cc];
-            vmax = std::max(vmax, std::sqrt(fro));
+            vm = std::max(1.0, std::sqrt(fro));
+            for (int k = 0; k < 4; k++) vm = std::max(vm, vlen(linear_dir(I, cam_dir[k])));
         }
-        if (!(vmax < 1e15)) vmax = 1e15;
-        vmax *= 1.0 + 1e-3;
+        vm = clamp_big(vm, 1e15) * (1.0 + 1e-3);
+        const double ext = widen(clamp_big(xf_extent[t], 1e30));
+        mag0[t] = {ob, vm, std::sqrt(3.0) * std::max(ob, ext)};
+        mag1[t] = {world_ob, 1.0 + 1e-3, std::sqrt(3.0) * std::max(world_ob, ext)};
+        R_max = std::max(R_max, std::max(mag0[t].R, mag1[t].R));
     }
 
-    // ---- filter thresholds (error analysis in DESIGN.md; every constant is rounded up) ----
+    // ---- filter thresholds (every constant is rounded up) ----
     const double EPSF = 1.1920928955078125e-7;   // 2^-23
-    const double Eb = 8 * EPSF * vmax;
-    const double Ea = 16 * EPSF * R;
-    auto thresholds = [&](float eps) {
-        FilterParams f{};
+    // amp_out: position-error amplification of the most grazing ray the reference still accepts
+    auto thresholds = [&](float eps, const Mag& m, double* amp_out) {
+        GroupFilter f{};
+        const double Eb = 8 * EPSF * m.vm, Ea = 16 * EPSF * m.R;
         double b_lo = (double)eps * (1 - 1e-3) - Eb;
         double r_lo = (double)eps * (1 - 1e-3) - 4 * (Ea + (double)eps * Eb) / std::max(b_lo, 1e-30);
-        if (!(b_lo > 0)) { b_lo = 0; r_lo = -FLT_MAX; }      // filter degenerates to "keep everything grazing"
-        f.b_lo = (float)b_lo; f.r_lo = (float)r_lo; f.a_zero = (float)(2 * Ea);
+        if (!(b_lo > 0)) { b_lo = 0; r_lo = -FLT_MAX; }      // nothing is certain about grazing rays
+        f.r_lo = (float)std::max(r_lo, -(double)FLT_MAX);
+        f.a_zero = (float)(2 * Ea * (1 + 1e-6));
+        f.b_hi = (float)(((double)std::fabs(eps) + Eb) * (1 + 1e-3));
+        f.origin_bound = (float)(m.ob * (1 - 1e-6));
+        f.dir_len2_bound = (float)(m.vm * m.vm * (1 - 1e-6));
+        *amp_out = 18.0 * m.vm / std::max(b_lo, 1e-30) + 20.0;
         return f;
     };
-    const FilterParams fpc = thresholds(d->eps), fps = thresholds(d->shadow_eps);
-    const double b_lo_min = std::max(1e-30, (double)std::min(fpc.b_lo, fps.b_lo));
-    const double amp = 18.0 * vmax / b_lo_min + 20.0;          // position-error amplification of a grazing ray
+    c->h_q0.resize(std::max(NX, 1)); c->h_q1.resize(std::max(NX, 1));
+    std::vector<double> amp0(std::max(NX, 1)), amp1(std::max(NX, 1));
+    for (int t = 0; t < NX; t++) {
+        c->h_q0[t] = thresholds(d->eps, mag0[t], &amp0[t]);
+        c->h_q1[t] = thresholds(d->shadow_eps, mag1[t], &amp1[t]);
+    }
 
-    // ---- triangles: reference-precision records, filter planes, regular / irregular split ----
-    struct TriTmp { TriExact ex; float f[16]; bool regular; int xf; int axis; };
-    std::vector<TriTmp> tris;
+    // ---- triangles: reference-precision records and both forms of the filter record ----
+    std::vector<HostTri>& tris = c->h_tris;
     std::vector<SphereRec> sph;
-    std::vector<int32_t> slot(N, -1);
+    c->h_slot.assign(N, -1);
     for (int i = 0; i < N; i++) {
         const double* g = d->obj_geom + 9 * (size_t)i;
         if (d->obj_kind[i] == 1) {
@@ -544,11 +672,11 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
             float radius = (float)g[3];
             s.r2 = (double)radius * (double)radius;
             s.obj = i; s.xf = d->obj_transform[i]; s.identity = xf_ident[s.xf];
-            slot[i] = (int32_t)sph.size();
+            c->h_slot[i] = (int32_t)sph.size();
             sph.push_back(s);
             continue;
         }
-        TriTmp t{};
+        HostTri t{};
         t.xf = d->obj_transform[i];
         Vec v1{g[0], g[1], g[2]}, v2{g[3], g[4], g[5]}, v3{g[6], g[7], g[8]};
         Vec e1 = vsub(v3, v1), e2 = vsub(v2, v1);                  // raytracer.cpp:288-289
@@ -602,83 +730,65 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
                     coef[q][2] = off3[q] + pc[k] * d0 / nn[k];
                     norm2d[q] = std::sqrt(coef[q][0] * coef[q][0] + coef[q][1] * coef[q][1]);
                 }
-                // rounding of the FP32 filter itself (hit position and plane evaluation)
-                double dAs = EPSF * norm2d[0] * R * amp, dAt = EPSF * norm2d[1] * R * amp;
-                double ds = 4 * (dAs + dBs) + 1e-6, dt = 4 * (dAt + dBt) + 1e-6, du = ds + dt;
-                ok = std::isfinite(ds) && std::isfinite(dt) && du < 1e6;
-                float* f = t.f;
-                f[0] = (float)n.x; f[1] = (float)n.y; f[2] = (float)n.z; f[3] = (float)d0;
-                f[4] = (float)coef[0][0]; f[5] = (float)coef[0][1]; f[6] = (float)(coef[0][2] + ds);
-                f[7] = (float)coef[1][0]; f[8] = (float)coef[1][1]; f[9] = (float)(coef[1][2] + dt);
-                f[10] = (float)coef[2][0]; f[11] = (float)coef[2][1]; f[12] = (float)(coef[2][2] + du);
-                f[13] = f[14] = f[15] = 0.f;
-                for (int q = 0; q < 13; q++) ok = ok && std::isfinite(f[q]);
+                const Mag& m0 = mag0[t.xf];
+                const Mag& m1 = mag1[t.xf];
+                for (int form = 0; form < 2; form++) {
+                    float* f = form ? t.f_robust : t.f_static;
+                    f[0] = (float)n.x; f[1] = (float)n.y; f[2] = (float)n.z; f[3] = (float)d0;
+                    double ds, dt;
+                    if (form == 0) {
+                        // rounding of the FP32 filter itself (hit position and plane evaluation), worst
+                        // case over both kinds of query and every ray
+                        const double RA = std::max(m0.R * amp0[t.xf], m1.R * amp1[t.xf]);
+                        ds = 4 * (EPSF * norm2d[0] * RA + dBs) + 1e-6;
+                        dt = 4 * (EPSF * norm2d[1] * RA + dBt) + 1e-6;
+                        f[13] = f[14] = 0.f;
+                    } else {
+                        // the same bound with the ray's own 1/|n.dir| in place of the worst case:
+                        // 18 vm/|b| + 20 <= 40 vm/|b| because |b| <= vm; the factor is applied per test
+                        ds = 4 * dBs + 1e-6;
+                        dt = 4 * dBt + 1e-6;
+                        const double nsum = norm2d[0] + norm2d[1];
+                        f[13] = (float)(4 * EPSF * nsum * m0.R * 42.0 * m0.vm);
+                        f[14] = (float)(4 * EPSF * nsum * m1.R * 42.0 * m1.vm);
+                    }
+                    const double du = ds + dt;
+                    bool fok = std::isfinite(ds) && std::isfinite(dt) && du < 1e6;
+                    f[4] = (float)coef[0][0]; f[5] = (float)coef[0][1]; f[6] = (float)(coef[0][2] + ds);
+                    f[7] = (float)coef[1][0]; f[8] = (float)coef[1][1]; f[9] = (float)(coef[1][2] + dt);
+                    f[10] = (float)coef[2][0]; f[11] = (float)coef[2][1]; f[12] = (float)(coef[2][2] + du);
+                    f[15] = 0.f;
+                    for (int q = 0; q < 15; q++) fok = fok && std::isfinite(f[q]);
+                    (form ? t.ok_robust : t.ok_static) = fok;
+                    if (form == 0) t.margin_static = (float)std::min(du, 1e30);
+                }
             }
         }
-        t.regular = ok;
         tris.push_back(t);
     }
+    c->h_xf_ident = xf_ident;
+    c->scene_bound = R_max;
 
-    // ---- order: regular triangles grouped by transform (stable), then the irregular ones likewise ----
-    std::vector<int> order_reg, order_irr;
-    for (int k = 0; k < (int)tris.size(); k++) (tris[k].regular ? order_reg : order_irr).push_back(k);
-    auto by_xf = [&](int a, int b) { return tris[a].xf < tris[b].xf; };
-    auto by_xf_axis = [&](int a, int b) {
-        return tris[a].xf != tris[b].xf ? tris[a].xf < tris[b].xf : tris[a].axis < tris[b].axis;
-    };
-    std::stable_sort(order_reg.begin(), order_reg.end(), by_xf_axis);
-    std::stable_sort(order_irr.begin(), order_irr.end(), by_xf);
-    const int NR = (int)order_reg.size(), NI = (int)order_irr.size();
-    std::vector<v16f> filt((size_t)NR + 1);          // + one readable padding record
-    std::memset(filt.data(), 0, filt.size() * sizeof(v16f));
-    std::vector<TriExact> exact((size_t)NR + NI);
-    for (int k = 0; k < NR; k++) {
-        const TriTmp& t = tris[order_reg[k]];
-        for (int j = 0; j < 16; j++) filt[k][j] = t.f[j];
-        exact[k] = t.ex;
-        slot[t.ex.obj] = k;
-    }
-    for (int k = 0; k < NI; k++) {
-        const TriTmp& t = tris[order_irr[k]];
-        exact[(size_t)NR + k] = t.ex;
-        slot[t.ex.obj] = NR + k;
-    }
-    std::vector<Group> groups;
+    // ---- which form of the filter: the cheap static margins unless they are useless here ----
     {
-        int r = 0, q = 0;
-        while (r < NR || q < NI) {
-            int xr = r < NR ? tris[order_reg[r]].xf : INT32_MAX;
-            int xq = q < NI ? tris[order_irr[q]].xf : INT32_MAX;
-            int x = std::min(xr, xq);
-            Group G{};
-            G.xf = x; G.identity = xf_ident[x];
-            for (int a = 0; a < 3; a++) {
-                G.fax[a] = r;
-                while (r < NR && tris[order_reg[r]].xf == x && tris[order_reg[r]].axis == a) r++;
+        double sum = 0; size_t n_ok = 0, n_only_robust = 0;
+        std::unordered_map<unsigned long long, int> planes;
+        int largest_plane = 0;
+        for (const HostTri& t : tris) {
+            if (t.ok_robust && !t.ok_static) n_only_robust++;
+            if (!t.ok_static) continue;
+            sum += std::min((double)t.margin_static, 100.0); n_ok++;
+            // triangles lying in one plane: a ray leaving that plane lists them all in the static form
+            const float* f = t.f_static;
+            unsigned long long key = (unsigned long long)(unsigned int)t.xf * 0x9E3779B97F4A7C15ull;
+            for (int q = 0; q < 4; q++) {
+                const double scale = q < 3 ? 2048.0 : 2048.0 / std::max(mag0[t.xf].R, 1e-30);
+                key = (key ^ (unsigned long long)(long long)std::llround(f[q] * scale)) * 0x100000001B3ull;
             }
-            G.fax[3] = r;
-            G.ibeg = NR + q;
-            while (q < NI && tris[order_irr[q]].xf == x) q++;
-            G.iend = NR + q;
-            for (int k2 = G.fax[0]; k2 < G.fax[3]; k2++) exact[k2].grp = (int32_t)groups.size();
-            for (int k2 = G.ibeg; k2 < G.iend; k2++) exact[k2].grp = (int32_t)groups.size();
-            groups.push_back(G);
+            largest_plane = std::max(largest_plane, ++planes[key]);
         }
-    }
-
-    c->h_groups = groups;
-    c->scene_bound = R;
-    c->h_centroid_box.assign(6 * groups.size(), 0.f);
-    for (size_t gi = 0; gi < groups.size(); gi++) {
-        float* bx = &c->h_centroid_box[6 * gi];
-        for (int a = 0; a < 3; a++) { bx[a] = FLT_MAX; bx[3 + a] = -FLT_MAX; }
-        for (int k2 = groups[gi].fax[0]; k2 < groups[gi].fax[3]; k2++) {
-            const TriExact& ex = exact[k2];
-            for (int a = 0; a < 3; a++) {
-                float cc = (float)(ex.v1[a] + (ex.e1[a] + ex.e2[a]) * (1.0 / 3.0));
-                bx[a] = std::min(bx[a], cc); bx[3 + a] = std::max(bx[3 + a], cc);
-            }
-        }
+        const double mean_margin = n_ok ? sum / (double)n_ok : 0.0;
+        c->auto_robust = (n_only_robust > 0 || mean_margin > 1.0 || largest_plane > 16) ? 1 : 0;
     }
 
     std::vector<DevMaterial> mats(d->n_materials);
@@ -700,33 +810,29 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
         hipError_t e_ = c->buf.upload(vec);                                                            \
         if (e_ != hipSuccess) return bail(fail(RT_ERR_DEVICE, std::string("upload " #buf ": ") + hipGetErrorString(e_))); \
     } while (0)
-    UP(tri_filt, filt); UP(tri_exact, exact); UP(spheres, sph); UP(groups, groups); UP(xforms, xf);
-    UP(xf_identity, xf_ident); UP(obj_kind, kind); UP(obj_slot, slot); UP(obj_material, omat);
+    UP(spheres, sph); UP(xforms, xf);
+    UP(xf_identity, xf_ident); UP(obj_kind, kind); UP(obj_material, omat);
     UP(obj_transform, oxf); UP(obj_interp, ointerp); UP(obj_geom, geom); UP(obj_normals, nrm);
     UP(materials, mats); UP(lights, lights);
 #undef UP
 
     DevScene& s = c->hs;
-    s.tri_filt = c->tri_filt.p; s.tri_exact = c->tri_exact.p; s.spheres = c->spheres.p; s.groups = c->groups.p;
-    s.xforms = c->xforms.p; s.xf_identity = c->xf_identity.p; s.obj_kind = c->obj_kind.p; s.obj_slot = c->obj_slot.p;
+    s.spheres = c->spheres.p;
+    s.xforms = c->xforms.p; s.xf_identity = c->xf_identity.p; s.obj_kind = c->obj_kind.p;
     s.obj_material = c->obj_material.p; s.obj_transform = c->obj_transform.p; s.obj_interp = c->obj_interp.p;
     s.obj_geom = c->obj_geom.p; s.obj_normals = c->obj_normals.p; s.materials = c->materials.p; s.lights = c->lights.p;
-    s.n_regular = NR; s.n_irregular = NI; s.n_spheres = (int)sph.size(); s.n_groups = (int)groups.size();
+    s.n_spheres = (int)sph.size();
     s.n_objects = N; s.n_lights = d->n_lights; s.n_transforms = NX;
     s.last_xf = N > 0 ? d->obj_transform[N - 1] : 0;
     s.width = d->width; s.height = d->height; s.max_depth = d->max_depth;
     s.eps = d->eps; s.shadow_eps = d->shadow_eps;
-    s.origin_bound = (float)origin_bound;
-    s.dir_len2_bound = (float)(vmax * vmax);
-    s.fp_closest = fpc; s.fp_shadow = fps;
     std::memcpy(s.cam_eye, d->cam_eye, 24); std::memcpy(s.cam_ll, d->cam_ll, 24); std::memcpy(s.cam_lr, d->cam_lr, 24);
     std::memcpy(s.cam_ul, d->cam_ul, 24); std::memcpy(s.cam_ur, d->cam_ur, 24); std::memcpy(s.ambient, d->ambient, 24);
     // the shading ray of an empty transform table cannot occur: N > 0 implies NX > 0
 
-    std::vector<DevScene> one(1, s);
-    hipError_t e = c->d_scene.upload(one);
-    if (e != hipSuccess) return bail(fail(RT_ERR_DEVICE, std::string("upload scene: ") + hipGetErrorString(e)));
-    e = c->own_frame.alloc((size_t)d->width * d->height);
+    // triangle records, groups and the scene header, in the form chosen above
+    if (int rc = install_filter(c, c->auto_robust)) return bail(rc);
+    hipError_t e = c->own_frame.alloc((size_t)d->width * d->height);
     if (e != hipSuccess) return bail(fail(RT_ERR_DEVICE, std::string("frame: ") + hipGetErrorString(e)));
     c->frame = c->own_frame.p;
     e = hipMemset(c->frame, 0, (size_t)d->width * d->height * 4);
@@ -738,8 +844,8 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
     for (int m = 0; m < 2; m++) {
         int nb = 0;
         hipError_t oe = (m == 0)
-            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_filter<0, RT_RPL>, RT_BLOCK, 0)
-            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_filter<1, RT_RPL>, RT_BLOCK, 0);
+            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_filter<0, RT_RPL, true>, RT_BLOCK, 0)
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_filter<1, RT_RPL, true>, RT_BLOCK, 0);
         if (oe != hipSuccess || nb < 1) nb = 2;
         c->filter_grid[m] = c->n_cu * std::min(nb, 8);
     }
@@ -757,6 +863,16 @@ int rt_set_option(rt_ctx* c, int option, int64_t value) {
             if (value < 1) return fail(RT_ERR_ARG, "rt_set_option: pass pixels must be positive");
             c->pass_pixels = value;
             return 0;
+        case RT_OPT_FILTER_FORM: {
+            if (value < 0 || value > 2) return fail(RT_ERR_ARG, "rt_set_option: filter form is 0 (auto), 1 (static) or 2 (per-test)");
+            const int want = value == 0 ? c->auto_robust : (value == 2 ? 1 : 0);
+            if (want == c->robust) return 0;
+            const int had_bvh = c->use_bvh;
+            int rc = install_filter(c, want);
+            if (rc) return rc;
+            if (had_bvh) return build_bvh(c);
+            return 0;
+        }
         case RT_OPT_USE_BVH:
             if (value) {
                 int rc = build_bvh(c);
@@ -822,6 +938,7 @@ int rt_get_stats(rt_ctx* c, rt_stats* out) {
     out->exact_ms = c->ms[2]; out->exact_launches = c->launches[2];
     out->n_triangles = c->hs.n_regular + c->hs.n_irregular; out->n_spheres = c->hs.n_spheres;
     out->n_groups = c->hs.n_groups; out->n_irregular = c->hs.n_irregular;
+    out->filter_form = c->robust ? 2 : 1;
     return 0;
 }
 

@@ -152,24 +152,29 @@ __global__ void k_bvh_refit(const TriExact* __restrict__ exact, const int* __res
 struct BvhCounters { unsigned long long node_tests, leaf_tests; };
 
 // The brute-force filter's test for ONE ray and a triangle record fetched per lane.
+// (Same arithmetic as filter_keep2; `robust` and `mode` select the per-test margin f[13 + mode].)
 __device__ __forceinline__ bool filter_keep1(const float* __restrict__ f, int axis, float px, float py, float pz,
-                                             float vx, float vy, float vz, const float rlo, const float az) {
+                                             float vx, float vy, float vz, const float rlo, const float az,
+                                             const float bhi, const bool robust, const int mode) {
     float b = f[0] * vx;
     b = __builtin_fmaf(f[1], vy, b);
     b = __builtin_fmaf(f[2], vz, b);
     float a = __builtin_fmaf(-f[0], px, f[3]);
     a = __builtin_fmaf(-f[1], py, a);
     a = __builtin_fmaf(-f[2], pz, a);
-    const float r = a * __builtin_amdgcn_rcpf(b);
+    const float rinv = __builtin_amdgcn_rcpf(b);
+    const float r = a * rinv;
     const float pu = axis == 0 ? py : (axis == 1 ? pz : px), pv = axis == 0 ? pz : (axis == 1 ? px : py);
     const float vu = axis == 0 ? vy : (axis == 1 ? vz : vx), vv = axis == 0 ? vz : (axis == 1 ? vx : vy);
     const float hu = __builtin_fmaf(r, vu, pu), hv = __builtin_fmaf(r, vv, pv);
     const float s = __builtin_fmaf(f[4], hu, __builtin_fmaf(f[5], hv, f[6]));
     const float t = __builtin_fmaf(f[7], hu, __builtin_fmaf(f[8], hv, f[9]));
     const float u = __builtin_fmaf(f[10], hu, __builtin_fmaf(f[11], hv, f[12]));
-    const float m = __builtin_fminf(__builtin_fminf(s, t), u);
+    float m = __builtin_fminf(__builtin_fminf(s, t), u);
+    if (robust) m = __builtin_fmaf(f[13 + mode], fabsf(rinv), m);
     const bool reject = (m < 0.0f) | (r < rlo);
-    return (!reject) | (fabsf(a) <= az);
+    const bool in_plane = robust ? ((fabsf(a) <= az) & (fabsf(b) <= bhi)) : (fabsf(a) <= az);
+    return (!reject) | in_plane;
 }
 
 // Can the half-line P + tV, t >= 0, reach the (already padded) box?  NaNs (0 * inf on a slab
@@ -198,8 +203,7 @@ k_bvh_trace(const DevScene* __restrict__ sc, const GroupBvh* __restrict__ bvh, c
     const unsigned int n_lights = sc->n_lights;
     const unsigned int n_hits = __builtin_amdgcn_readfirstlane(*A.n_items);
     const unsigned int n_rays = (MODE == 0) ? n_hits : n_hits * n_lights;
-    const FilterParams fp = (MODE == 0) ? sc->fp_closest : sc->fp_shadow;
-    const float ob = sc->origin_bound, vb = sc->dir_len2_bound;
+    const bool robust = sc->robust_filter != 0;
     const int n_groups = sc->n_groups;
     unsigned long long n_node = 0, n_leaf = 0;
 
@@ -216,6 +220,8 @@ k_bvh_trace(const DevScene* __restrict__ sc, const GroupBvh* __restrict__ bvh, c
             const Group& G = sc->groups[g];
             const GroupBvh B = bvh[g];
             if (B.n <= 0) continue;
+            const GroupFilter fp = G.q[MODE];
+            const float ob = fp.origin_bound, vb = fp.dir_len2_bound;
             d3 pos = wpos, vec = wvec;
             if (MODE == 0) to_object_space(sc->xforms + 48 * (size_t)G.xf, G.identity, &pos, &vec);
             const float px = (float)pos.x, py = (float)pos.y, pz = (float)pos.z;
@@ -232,14 +238,15 @@ k_bvh_trace(const DevScene* __restrict__ sc, const GroupBvh* __restrict__ bvh, c
                     const int slot = -1 - cur;
                     const int axis = slot >= fax2 ? 2 : (slot >= fax1 ? 1 : 0);
                     n_leaf++;
-                    if (filter_keep1(filt + 16 * (size_t)slot, axis, px, py, pz, vx, vy, vz, fp.r_lo, fp.a_zero)) {
+                    if (filter_keep1(filt + 16 * (size_t)slot, axis, px, py, pz, vx, vy, vz, fp.r_lo, fp.a_zero, fp.b_hi, robust,
+                                     MODE)) {
                         if (n_staged == RT_BVH_STAGE) {
                             // staging full: this lane appends its entries on its own (rare), then goes on
-                            const unsigned int base = atomicAdd(A.pair_count, (unsigned int)RT_BVH_STAGE);
-                            if (base + RT_BVH_STAGE > A.pair_cap || base + RT_BVH_STAGE < base) bail = true;
-                            else
-                                for (int k = 0; k < RT_BVH_STAGE; k++)
-                                    A.pairs[base + k] = ((unsigned long long)ray << 32) | my_stage[k * RT_BVH_BLOCK];
+                            const unsigned long long base = atomicAdd(A.pair_count, (unsigned long long)RT_BVH_STAGE);
+                            if (base + RT_BVH_STAGE > A.pair_cap) bail = true;
+                            // entries that still fit are written even then: no unwritten slot below pair_cap
+                            for (int k = 0; k < RT_BVH_STAGE && base + k < A.pair_cap; k++)
+                                A.pairs[base + k] = ((unsigned long long)ray << 32) | my_stage[k * RT_BVH_BLOCK];
                             n_staged = 0;
                         }
                         my_stage[n_staged * RT_BVH_BLOCK] = (unsigned int)slot;
@@ -276,16 +283,11 @@ k_bvh_trace(const DevScene* __restrict__ sc, const GroupBvh* __restrict__ bvh, c
         }
         const int total = __shfl(incl, RT_WAVE - 1);
         if (total > 0) {
-            unsigned int base = 0;
-            if (lane == 0) base = atomicAdd(A.pair_count, (unsigned int)total);
-            base = __shfl(base, 0);
-            if (base + (unsigned int)total > A.pair_cap || base + (unsigned int)total < base) {
-                if (valid && n_staged > 0) A.ray_flags[ray] = 1;
-            } else {
-                unsigned long long* out = A.pairs + base + (unsigned int)(incl - n_staged);
-                for (int k = 0; k < n_staged; k++)
-                    out[k] = ((unsigned long long)ray << 32) | my_stage[k * RT_BVH_BLOCK];
-            }
+            const unsigned long long base = wave_append(A.pair_count, (unsigned int)total, lane);
+            const unsigned long long first = base + (unsigned int)(incl - n_staged);
+            if (base + (unsigned int)total > A.pair_cap && valid && n_staged > 0) A.ray_flags[ray] = 1;
+            for (int k = 0; k < n_staged && first + k < A.pair_cap; k++)
+                A.pairs[first + k] = ((unsigned long long)ray << 32) | my_stage[k * RT_BVH_BLOCK];
         }
     }
     for (int off = 32; off > 0; off >>= 1) { n_node += __shfl_xor(n_node, off); n_leaf += __shfl_xor(n_leaf, off); }

@@ -36,6 +36,19 @@ struct __attribute__((aligned(16))) SphereRec {
     int32_t obj, xf, identity, pad;
 };
 
+// Thresholds of the FP32 candidate filter for one kind of query against one transform
+// group.  A pair (ray, triangle) may be dropped only when the reference-precision test is
+// certain to miss; the thresholds follow from the magnitudes the group's rays and vertices
+// can have (derived on the host when the scene is uploaded).
+struct GroupFilter {
+    float r_lo;            // ray parameter below this: the reference's r < eps reject is certain
+    float a_zero;          // |plane distance of the origin| at or below this: a == 0.0f is possible
+    float b_hi;            // |n.dir| above this: the reference's grazing branch (raytracer.cpp:319) is not taken
+    float origin_bound;    // the thresholds hold for rays with |origin component| <= this
+    float dir_len2_bound;  // ... and |dir|^2 <= this; other rays take the reference-precision scan
+    float pad[3];
+};
+
 // Triangles that share one transform.  Filter slots [fax[0], fax[3]) are regular
 // triangles; exact slots [ibeg, iend) hold the group's irregular triangles
 // (degenerate, non-finite, or too ill-conditioned for the FP32 filter), which
@@ -44,20 +57,12 @@ struct Group {
     int32_t xf, identity;
     int32_t fax[4];    // filter slots [fax[k], fax[k+1]): triangles whose normal's dominant axis is k
     int32_t ibeg, iend;
+    GroupFilter q[2];  // [0] nearest hit: rays in the group's object space (Scene::eps);
+                       // [1] shadow: world-space rays against the untransformed vertices (0.1f)
 };
 
 struct DevMaterial { double ka[3], kd[3], ks[3], kr[3]; double sp; };
 struct DevLight { double color[3], pos[3]; int32_t falloff, is_point; };
-
-// Thresholds of the FP32 candidate filter for one kind of query (nearest hit
-// uses Scene::eps, shadow rays 0.1f).  A pair (ray, triangle) may be dropped
-// only when the reference-precision test is certain to miss.
-struct FilterParams {
-    float b_lo;      // |n.dir| below this: the reference's grazing reject is certain
-    float r_lo;      // ray parameter below this: the reference's r < eps reject is certain
-    float a_zero;    // |plane distance of the origin| at or below this: a == 0.0f is possible
-    float pad;
-};
 
 struct DevScene {
     const v16f* tri_filt;        // [n_regular + 1]: one padding record at the end
@@ -79,9 +84,8 @@ struct DevScene {
     int32_t n_objects, n_lights, n_transforms, last_xf;
     int32_t width, height, max_depth, pad0;
     float eps, shadow_eps;
-    float origin_bound;          // filter trusted only for |origin component| <= this
-    float dir_len2_bound;        // ... and |dir|^2 <= this
-    FilterParams fp_closest, fp_shadow;
+    int32_t robust_filter;       // 1: filter records carry per-test margins (see filter_keep2)
+    int32_t pad1;
     double cam_eye[3], cam_ll[3], cam_lr[3], cam_ul[3], cam_ur[3];
     double ambient[3];
 };

@@ -115,7 +115,7 @@ struct TraceArgs {
     int32_t scan_all;                    // k_brute: 1 = test every triangle for every ray (filter switched off)
     uint8_t* ray_flags;                  // per ray: 1 = k_brute must scan every triangle for it
     unsigned long long* pairs;           // (ray << 32) | exact-record slot
-    unsigned int* pair_count;            // pairs appended so far (may run past pair_cap: the surplus is dropped)
+    unsigned long long* pair_count;      // pairs appended so far (may run past pair_cap: the surplus is dropped)
     unsigned int* task_counter;          // k_filter: next task to hand out (zeroed before the launch)
     unsigned int pair_cap;
     DevCounters* counters;
@@ -176,7 +176,7 @@ __device__ __forceinline__ void publish_result(const TraceArgs& A, unsigned int 
 //             normal's dominant axis (the third follows from the plane equation),
 //   f[7..9]   t likewise, f[10..12] u = 1 - s - t likewise; every offset includes the margin.
 // (pu, pv, vu, vv): those two coordinates of the ray origin and direction.
-// rlo / az: the query's thresholds (FilterParams).
+// Q: the query's thresholds for the triangle's group (GroupFilter).
 // Every comparison is false for NaN, so NaN never rejects.  A ray too parallel to the plane
 // needs no test of its own: the reference then misses unless the origin lies on the plane
 // (raytracer.cpp:319-325), which the last term keeps.
@@ -184,8 +184,19 @@ __device__ __forceinline__ void publish_result(const TraceArgs& A, unsigned int 
 // instructions (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth of FMAs per issue slot), so the
 // lane's rays are kept as float2 pairs and every multiply-add of the test is a packed one.
 // Reciprocal, min3 and the comparisons have no packed form and stay per ray.
+//
+// ROBUST = false: the margins in the offsets are the worst case over every ray the group can
+// meet (the most grazing one included) -- the cheapest test, right for scenes whose triangles
+// are large against the FP32 resolution of the scene.
+// ROBUST = true: the offsets carry only the ray-independent part; the part that grows with
+// 1/|n.dir| is added per test from f[13 + MODE] (nearest hit / shadow), and the in-plane-origin
+// term also requires a grazing ray, so a ray leaving a flat wall does not list every triangle
+// of that wall.  Two more instructions per ray; chosen per scene when it is uploaded.
+struct FilterQuery { float r_lo, a_zero, b_hi; };
+
+template <int MODE, bool ROBUST>
 __device__ __forceinline__ void filter_keep2(const v16f f, v2f px, v2f py, v2f pz, v2f vx, v2f vy, v2f vz,
-                                             v2f pu, v2f pv, v2f vu, v2f vv, const float rlo, const float az,
+                                             v2f pu, v2f pv, v2f vu, v2f vv, const FilterQuery Q,
                                              bool* keep0, bool* keep1) {
     const v2f n0 = {f[0], f[0]}, n1 = {f[1], f[1]}, n2 = {f[2], f[2]}, d0 = {f[3], f[3]};
     v2f b = n0 * vx;
@@ -204,12 +215,22 @@ __device__ __forceinline__ void filter_keep2(const v16f f, v2f px, v2f py, v2f p
     const v2f s = __builtin_elementwise_fma(c4, hu, __builtin_elementwise_fma(c5, hv, c6));
     const v2f t = __builtin_elementwise_fma(c7, hu, __builtin_elementwise_fma(c8, hv, c9));
     const v2f u = __builtin_elementwise_fma(c10, hu, __builtin_elementwise_fma(c11, hv, c12));
-    const float m0 = __builtin_fminf(__builtin_fminf(s.x, t.x), u.x);
-    const float m1 = __builtin_fminf(__builtin_fminf(s.y, t.y), u.y);
-    const bool reject0 = (m0 < 0.0f) | (r.x < rlo);
-    const bool reject1 = (m1 < 0.0f) | (r.y < rlo);
-    *keep0 = (!reject0) | (fabsf(a.x) <= az);
-    *keep1 = (!reject1) | (fabsf(a.y) <= az);
+    float m0 = __builtin_fminf(__builtin_fminf(s.x, t.x), u.x);
+    float m1 = __builtin_fminf(__builtin_fminf(s.y, t.y), u.y);
+    if (ROBUST) {
+        const float gm = f[13 + MODE];
+        m0 = __builtin_fmaf(gm, fabsf(rinv.x), m0);
+        m1 = __builtin_fmaf(gm, fabsf(rinv.y), m1);
+    }
+    const bool reject0 = (m0 < 0.0f) | (r.x < Q.r_lo);
+    const bool reject1 = (m1 < 0.0f) | (r.y < Q.r_lo);
+    if (ROBUST) {
+        *keep0 = (!reject0) | ((fabsf(a.x) <= Q.a_zero) & (fabsf(b.x) <= Q.b_hi));
+        *keep1 = (!reject1) | ((fabsf(a.y) <= Q.a_zero) & (fabsf(b.y) <= Q.b_hi));
+    } else {
+        *keep0 = (!reject0) | (fabsf(a.x) <= Q.a_zero);
+        *keep1 = (!reject1) | (fabsf(a.y) <= Q.a_zero);
+    }
 }
 
 template <int RPL> struct FilterLane {     // ray slots 2q and 2q+1 share a float2
@@ -220,7 +241,17 @@ template <int RPL> struct FilterLane {     // ray slots 2q and 2q+1 share a floa
 template <int AXIS> __device__ __forceinline__ v2f pick_u(v2f x, v2f y, v2f z) { return AXIS == 0 ? y : (AXIS == 1 ? z : x); }
 template <int AXIS> __device__ __forceinline__ v2f pick_v(v2f x, v2f y, v2f z) { return AXIS == 0 ? z : (AXIS == 1 ? x : y); }
 
-// Appends the lane's staged candidates (LDS) to the pair list: one atomic per wave.
+// Reserves `total` consecutive entries of the pair list for the wave: one atomic per wave.
+// The counter is 64 bits wide and keeps counting past pair_cap, so a full list stays full.
+__device__ __forceinline__ unsigned long long wave_append(unsigned long long* counter, unsigned int total, int lane) {
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(counter, (unsigned long long)total);
+    const unsigned int lo = (unsigned int)__shfl((int)(unsigned int)base, 0);
+    const unsigned int hi = (unsigned int)__shfl((int)(unsigned int)(base >> 32), 0);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// Appends the lane's staged candidates (LDS) to the pair list.
 template <int RPL>
 __device__ __forceinline__ void flush_candidates(const TraceArgs& A, const unsigned short* my_cand, int n_cand, int cbeg,
                                                  unsigned int ray0, unsigned int n_rays, int lane) {
@@ -232,31 +263,31 @@ __device__ __forceinline__ void flush_candidates(const TraceArgs& A, const unsig
         if (lane >= off) incl += up;
     }
     const int total = __shfl(incl, RT_WAVE - 1);
-    unsigned int base = 0;
-    if (lane == 0) base = atomicAdd(A.pair_count, (unsigned int)total);
-    base = __shfl(base, 0);
-    if (base + (unsigned int)total > A.pair_cap || base + (unsigned int)total < base) {
-        // list full: the surplus is dropped and every ray of this lane gets the full scan instead
+    const unsigned long long base = wave_append(A.pair_count, (unsigned int)total, lane);
+    const unsigned long long first = base + (unsigned int)(incl - n_cand);
+    if (base + (unsigned int)total > A.pair_cap) {
+        // List full: every ray of this lane that has a candidate gets the full scan instead.
+        // Entries that still fit are written all the same (they are valid pairs), so the list
+        // has no unwritten slot below pair_cap.
 #pragma unroll
         for (int r = 0; r < RPL; r++) {
             const unsigned int ray = ray0 + r * RT_WAVE;
             if (ray < n_rays && n_cand > 0) A.ray_flags[ray] = 1;
         }
-        return;
     }
-    unsigned long long* out = A.pairs + base + (unsigned int)(incl - n_cand);
     for (int k = 0; k < n_cand; k++) {
+        if (first + k >= A.pair_cap) break;
         const unsigned int e = my_cand[k * RT_BLOCK];
         const unsigned int r = e >> SLOT_SHIFT;
         const unsigned int slot = (unsigned int)cbeg + (e & ((1u << SLOT_SHIFT) - 1u));
-        out[k] = ((unsigned long long)(ray0 + r * RT_WAVE) << 32) | slot;
+        A.pairs[first + k] = ((unsigned long long)(ray0 + r * RT_WAVE) << 32) | slot;
     }
 }
 
 // Filter loop over the regular triangles [abeg, aend) whose normals share the dominant axis AXIS.
-template <int MODE, int RPL, int AXIS>
+template <int MODE, int RPL, int AXIS, bool ROBUST>
 __device__ __forceinline__ void filter_range(const cv16f* filt, const TraceArgs& A, const FilterLane<RPL>& L,
-                                             const FilterParams fp, int abeg, int aend, unsigned short* my_cand,
+                                             const FilterQuery fp, int abeg, int aend, unsigned short* my_cand,
                                              unsigned int ray0, unsigned int n_rays, int lane) {
     constexpr int SLOT_SHIFT = RT_SLOT_SHIFT(RPL);
     constexpr int CHUNK = 1 << SLOT_SHIFT;
@@ -279,8 +310,8 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const TraceArgs&
                 bool keep[RPL], any = false;
 #pragma unroll
                 for (int q = 0; q < RPL / 2; q++) {
-                    filter_keep2(cur, L.px[q], L.py[q], L.pz[q], L.vx[q], L.vy[q], L.vz[q], pu[q], pv[q], vu[q], vv[q],
-                                 fp.r_lo, fp.a_zero, &keep[2 * q], &keep[2 * q + 1]);
+                    filter_keep2<MODE, ROBUST>(cur, L.px[q], L.py[q], L.pz[q], L.vx[q], L.vy[q], L.vz[q], pu[q], pv[q],
+                                               vu[q], vv[q], fp, &keep[2 * q], &keep[2 * q + 1]);
                     any |= keep[2 * q] | keep[2 * q + 1];
                 }
                 if (any) {               // rarely true for any lane of the wave
@@ -305,7 +336,11 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const TraceArgs&
     }
 }
 
-template <int MODE, int RPL>
+__device__ __forceinline__ float uniform_f(float x) {      // a value every lane of the wave holds: keep it scalar
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
+}
+
+template <int MODE, int RPL, bool ROBUST>
 __global__ void __launch_bounds__(RT_BLOCK, RT_FILTER_MIN_WAVES)
 k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, TraceArgs A) {
     // The filter records are never written while a kernel runs: reading them through the
@@ -337,8 +372,6 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
         if (split > max_split) split = max_split;
     }
     const unsigned int n_tasks = n_ray_blocks * (unsigned int)split;
-    const FilterParams fp = (MODE == 0) ? sc->fp_closest : sc->fp_shadow;
-    const float ob = sc->origin_bound, vb = sc->dir_len2_bound;
     const int n_groups = sc->n_groups;
 
     for (;;) {
@@ -368,6 +401,10 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
             const int ident = (MODE == 0) ? __builtin_amdgcn_readfirstlane(G.identity) : 1;
             const double* X = sc->xforms + 48 * (size_t)__builtin_amdgcn_readfirstlane(G.xf);
             if (fax[0] >= fax[3]) continue;
+            const GroupFilter& GQ = G.q[MODE];
+            const FilterQuery fp = {uniform_f(GQ.r_lo), uniform_f(GQ.a_zero), uniform_f(GQ.b_hi)};
+            // (shadow rays: every group carries the same two bounds, those of world-space rays)
+            const float ob = uniform_f(GQ.origin_bound), vb = uniform_f(GQ.dir_len2_bound);
             // FP32 copies of the lane's rays in this group's object space
             if (MODE == 0 || !have_rays) {
                 have_rays = true;
@@ -415,9 +452,9 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                 const int abeg = fax[axis] + part * per_part;
                 const int aend = min(fax[axis + 1], abeg + per_part);
                 if (abeg >= aend) continue;
-                if (axis == 0) filter_range<MODE, RPL, 0>(filt, A, L, fp, abeg, aend, my_cand, ray0, n_rays, lane);
-                if (axis == 1) filter_range<MODE, RPL, 1>(filt, A, L, fp, abeg, aend, my_cand, ray0, n_rays, lane);
-                if (axis == 2) filter_range<MODE, RPL, 2>(filt, A, L, fp, abeg, aend, my_cand, ray0, n_rays, lane);
+                if (axis == 0) filter_range<MODE, RPL, 0, ROBUST>(filt, A, L, fp, abeg, aend, my_cand, ray0, n_rays, lane);
+                if (axis == 1) filter_range<MODE, RPL, 1, ROBUST>(filt, A, L, fp, abeg, aend, my_cand, ray0, n_rays, lane);
+                if (axis == 2) filter_range<MODE, RPL, 2, ROBUST>(filt, A, L, fp, abeg, aend, my_cand, ray0, n_rays, lane);
             }
         }
     }
@@ -427,13 +464,18 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
 template <int MODE>
 __global__ void __launch_bounds__(RT_BLOCK)
 k_exact_pairs(const DevScene* __restrict__ sc, const TriExact* __restrict__ exact, TraceArgs A) {
-    const unsigned int listed = *A.pair_count;
-    const unsigned int n = listed < A.pair_cap ? listed : A.pair_cap;
+    const unsigned long long listed = *A.pair_count;
+    const unsigned int n = listed < A.pair_cap ? (unsigned int)listed : A.pair_cap;
     const unsigned int n_lights = sc->n_lights;
+    const unsigned int n_rays = (MODE == 0) ? *A.n_items : *A.n_items * n_lights;
+    const unsigned int n_regular = (unsigned int)sc->n_regular;
     const float eps = (MODE == 0) ? sc->eps : sc->shadow_eps;
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const unsigned long long pr = A.pairs[i];
         const unsigned int ray = (unsigned int)(pr >> 32), slot = (unsigned int)pr;
+        // Every entry below n was written by this launch's producers; the check only keeps a
+        // producer bug from turning into an out-of-range access.
+        if (ray >= n_rays || slot >= n_regular) continue;
         const TriExact& T = exact[slot];
         int ident = 1;
         const double* X = sc->xforms;

@@ -30,9 +30,13 @@ def scene_file(name):
     raise FileNotFoundError(name)
 
 
-def gpu_render(sc, exact_only=False, pass_pixels=None, tiles=None):
+def gpu_render(sc, exact_only=False, pass_pixels=None, tiles=None, filter_form=None, bvh=False):
     from raytracer_amd.render import Renderer
     r = Renderer(sc)
+    if filter_form is not None:
+        r.set_option(abi.RT_OPT_FILTER_FORM, filter_form)
+    if bvh:
+        r.set_option(abi.RT_OPT_USE_BVH, 1)
     if exact_only:
         r.set_option(abi.RT_OPT_EXACT_ONLY, 1)
     if pass_pixels:
@@ -76,12 +80,29 @@ def test_exact_only_mode_equals_filtered_mode(name, w, h, depth):
     """The FP32 filter may only drop pairs the reference-precision test would reject:
     switching it off must not change a single byte, nor any count."""
     sc = Scene.load(scene_file(name), w, h, depth)
-    a, sa = gpu_render(sc)
     b, sb = gpu_render(sc, exact_only=True)
-    assert np.array_equal(a, b)
-    for k in ("rays_primary", "rays_reflect", "rays_shadow", "hits"):
-        assert sa[k] == sb[k], k
-    assert sb["exact_tests"] >= sa["exact_tests"]
+    # both forms of the filter (static margins / per-test margins), brute force and LBVH
+    for form in (1, 2):
+        for bvh in (False, True):
+            a, sa = gpu_render(sc, filter_form=form, bvh=bvh)
+            assert sa["filter_form"] == form
+            assert np.array_equal(a, b), (form, bvh)
+            for k in ("rays_primary", "rays_reflect", "rays_shadow", "hits"):
+                assert sa[k] == sb[k], (k, form, bvh)
+            assert sb["exact_tests"] >= sa["exact_tests"]
+
+
+def test_filter_form_follows_the_scene():
+    """Large smooth triangles take the cheap static margins; a mesh of triangles that are tiny
+    against its scene, or that has walls of coplanar triangles, takes per-test margins and then
+    lists only a few pairs per ray instead of overflowing into the full scan."""
+    _, st = gpu_render(Scene.load(scene_file("teapot"), 96, 54, 2))
+    assert st["filter_form"] == 1 and st["flagged_rays"] == 0
+    _, st = gpu_render(Scene.load(scene_file("campanile_teddy"), 192, 108, 2))
+    assert st["filter_form"] == 2 and st["flagged_rays"] == 0
+    rays = st["rays_primary"] + st["rays_reflect"] + st["rays_shadow"]
+    # exact tests: the 50-odd irregular triangles for every ray, plus a few listed pairs
+    assert st["exact_tests"] < rays * (st["n_irregular"] + 16)
 
 
 @pytest.mark.parametrize("name,w,h,depth", [("input-11", 100, 80, 6), ("mixed_xf", 80, 60, 6), ("teapot", 48, 27, 5),
