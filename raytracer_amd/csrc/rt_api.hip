@@ -324,8 +324,11 @@ int build_bvh(rt_ctx* c) {
         if (n <= 1) continue;
         const float* bx = &c->h_centroid_box[6 * g];
         float3 cmin = make_float3(bx[0], bx[1], bx[2]);
-        float3 cscale = make_float3(bx[3] > bx[0] ? 1.0f / (bx[3] - bx[0]) : 0.f, bx[4] > bx[1] ? 1.0f / (bx[4] - bx[1]) : 0.f,
-                                    bx[5] > bx[2] ? 1.0f / (bx[5] - bx[2]) : 0.f);
+        // One scale for the three axes (the largest extent): a thin group -- a height field, a wall --
+        // is then split along the directions it extends in, not sliced into layers across the thin one.
+        const float ext = std::max(bx[3] - bx[0], std::max(bx[4] - bx[1], bx[5] - bx[2]));
+        const float sc1 = ext > 0.f ? 1.0f / ext : 0.f;
+        float3 cscale = make_float3(sc1, sc1, sc1);
         const int blocks = (n + 255) / 256;
         hipLaunchKernelGGL(k_bvh_morton, dim3(blocks), dim3(256), 0, 0, (const TriExact*)c->tri_exact.p, base, n, cmin,
                            cscale, keys_in.p, vals_in.p);
@@ -648,6 +651,8 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
         f.r_lo = (float)std::max(r_lo, -(double)FLT_MAX);
         f.a_zero = (float)(2 * Ea * (1 + 1e-6));
         f.b_hi = (float)(((double)std::fabs(eps) + Eb) * (1 + 1e-3));
+        f.e_a = (float)(Ea * (1 + 1e-6)); f.e_b = (float)(Eb * (1 + 1e-6));
+        f.r_hi = (float)((double)std::fabs(eps) * (1 + 1e-3));
         f.origin_bound = (float)(m.ob * (1 - 1e-6));
         f.dir_len2_bound = (float)(m.vm * m.vm * (1 - 1e-6));
         *amp_out = 18.0 * m.vm / std::max(b_lo, 1e-30) + 20.0;
@@ -757,8 +762,8 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
                     f[4] = (float)coef[0][0]; f[5] = (float)coef[0][1]; f[6] = (float)(coef[0][2] + ds);
                     f[7] = (float)coef[1][0]; f[8] = (float)coef[1][1]; f[9] = (float)(coef[1][2] + dt);
                     f[10] = (float)coef[2][0]; f[11] = (float)coef[2][1]; f[12] = (float)(coef[2][2] + du);
-                    f[15] = 0.f;
-                    for (int q = 0; q < 15; q++) fok = fok && std::isfinite(f[q]);
+                    f[15] = (float)(du * (1 + 1e-6));      // the largest margin folded into the offsets (LBVH pruning)
+                    for (int q = 0; q < 16; q++) fok = fok && std::isfinite(f[q]);
                     (form ? t.ok_robust : t.ok_static) = fok;
                     if (form == 0) t.margin_static = (float)std::min(du, 1e30);
                 }

@@ -1,11 +1,11 @@
 // Optional LBVH over the regular triangles of each transform group.
 //
 // The hierarchy is one more CONSERVATIVE filter in front of the reference-precision test:
-// traversal never orders or prunes by distance, it collects every triangle whose padded
-// box the ray's half-line can reach, runs the same FP32 triangle filter as the brute-force
-// scan on it, and appends the survivors to the same pair list.  k_exact_pairs / k_brute then
-// decide exactly as in brute-force mode, so the nearest hit (index and distance bits) is the
-// brute-force one.  The one reference behaviour a box hierarchy cannot reproduce is the
+// traversal collects the triangles whose padded box the ray's half-line can reach, runs the
+// same FP32 triangle filter as the brute-force scan on them, and gives the survivors to the
+// same reference-precision test (tri_intersect_exact).  It skips a box only when the ray
+// cannot reach it or when everything in it lies behind a hit that test has already accepted
+// (see k_bvh_trace), so the nearest hit (index and distance bits) is the brute-force one.  The one reference behaviour a box hierarchy cannot reproduce is the
 // in-plane-origin case of Triangle::intersection (raytracer.cpp:319-321: a == 0 with a
 // grazing ray "hits" the infinite plane, wherever the triangle is); rt_stats counts those
 // events in brute-force mode so a caller can tell whether a scene has any.
@@ -20,7 +20,8 @@
 
 #define RT_BVH_BLOCK 256
 #define RT_BVH_STACK 40         // per-lane traversal stack entries (LDS)
-#define RT_BVH_STAGE 8          // per-lane staged candidates (LDS)
+#define RT_BVH_STAGE 4          // per-lane staged candidates (LDS)
+#define RT_BVH_STEPS 8          // traversal steps between two drain phases
 
 struct __attribute__((aligned(16))) BvhNode {
     float lo[2][3], hi[2][3];   // boxes of the two children
@@ -151,11 +152,12 @@ __global__ void k_bvh_refit(const TriExact* __restrict__ exact, const int* __res
 
 struct BvhCounters { unsigned long long node_tests, leaf_tests; };
 
-// The brute-force filter's test for ONE ray and a triangle record fetched per lane.
-// (Same arithmetic as filter_keep2; `robust` and `mode` select the per-test margin f[13 + mode].)
+// The brute-force filter's test for ONE ray and a triangle record fetched per lane (same
+// arithmetic as filter_keep2; `robust` selects the per-test margin f[13 + mode]).
+// *r_lo_out: a lower bound of the ray parameter the reference would compute for the pair.
 __device__ __forceinline__ bool filter_keep1(const float* __restrict__ f, int axis, float px, float py, float pz,
-                                             float vx, float vy, float vz, const float rlo, const float az,
-                                             const float bhi, const bool robust, const int mode) {
+                                             float vx, float vy, float vz, const GroupFilter& Q, const bool robust,
+                                             const int mode, float* r_lo_out) {
     float b = f[0] * vx;
     b = __builtin_fmaf(f[1], vy, b);
     b = __builtin_fmaf(f[2], vz, b);
@@ -172,25 +174,43 @@ __device__ __forceinline__ bool filter_keep1(const float* __restrict__ f, int ax
     const float u = __builtin_fmaf(f[10], hu, __builtin_fmaf(f[11], hv, f[12]));
     float m = __builtin_fminf(__builtin_fminf(s, t), u);
     if (robust) m = __builtin_fmaf(f[13 + mode], fabsf(rinv), m);
-    const bool reject = (m < 0.0f) | (r < rlo);
-    const bool in_plane = robust ? ((fabsf(a) <= az) & (fabsf(b) <= bhi)) : (fabsf(a) <= az);
+    const bool reject = (m < 0.0f) | (r < Q.r_lo);
+    const bool in_plane = robust ? ((fabsf(a) <= Q.a_zero) & (fabsf(b) <= Q.b_hi)) : (fabsf(a) <= Q.a_zero);
+    // |r - reference's r| <= (Ea + |r| Eb) / |b| + rounding of the division and the product
+    *r_lo_out = r - ((Q.e_a + fabsf(r) * Q.e_b) * fabsf(rinv) * 1.25f + fabsf(r) * 1e-6f);
     return (!reject) | in_plane;
 }
 
-// Can the half-line P + tV, t >= 0, reach the (already padded) box?  NaNs (0 * inf on a slab
-// boundary) drop out of min/max, which only widens the interval.
+// Where the half-line P + tV, t >= 0, is inside the (already padded) box: false when it never
+// is, else *t_near = a lower bound of the entry parameter.  NaNs (0 * inf on a slab boundary)
+// drop out of min/max, which only widens the interval.
 __device__ __forceinline__ bool ray_reaches_box(const float* lo, const float* hi, float px, float py, float pz,
-                                                float ix, float iy, float iz) {
+                                                float ix, float iy, float iz, float* t_near) {
     const float x0 = (lo[0] - px) * ix, x1 = (hi[0] - px) * ix;
     const float y0 = (lo[1] - py) * iy, y1 = (hi[1] - py) * iy;
     const float z0 = (lo[2] - pz) * iz, z1 = (hi[2] - pz) * iz;
     float tnear = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
     float tfar = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-    tnear -= fabsf(tnear) * 1e-5f;
-    tfar += fabsf(tfar) * 1e-5f;
+    // widen by rounding slack; by multiplication, so that an infinite bound (zero direction
+    // component, box entirely to one side) stays infinite instead of turning into inf - inf
+    tnear *= (tnear > 0.0f) ? (1.0f - 1e-5f) : (1.0f + 1e-5f);
+    tfar *= (tfar > 0.0f) ? (1.0f + 1e-5f) : (1.0f - 1e-5f);
+    *t_near = tnear;
     return !(tnear > tfar) && !(tfar < 0.0f);
 }
 
+// One ray per lane, nodes visited nearer child first.  The wave alternates between a few
+// traversal steps and a drain phase in which every lane that has staged triangles (survivors
+// of the FP32 filter) runs the reference-precision test on them -- together, so that the
+// double-precision work is not serialised lane by lane.  What the exact test finds bounds
+// the rest of the search:
+//   nearest hit, identity-transform group: the metric of Scene::traceRay (raytracer.cpp:522-524)
+//     is |dir| * r there, monotone in the ray parameter r, so boxes and triangles that begin
+//     behind an accepted hit can neither hold the nearest hit nor tie with it;
+//   nearest hit, transformed group: the metric mixes spaces; nothing is pruned;
+//   shadow ray: the first accepted hit off the source object settles it (raytracer.cpp:553).
+// Results are merged exactly as k_exact_pairs does (atomicMin of the key / atomicOr of the
+// light's bit), so the other kernels of the launch need not know which path produced them.
 template <int MODE>
 __global__ void __launch_bounds__(RT_BVH_BLOCK)
 k_bvh_trace(const DevScene* __restrict__ sc, const GroupBvh* __restrict__ bvh, const float* __restrict__ filt,
@@ -205,94 +225,129 @@ k_bvh_trace(const DevScene* __restrict__ sc, const GroupBvh* __restrict__ bvh, c
     const unsigned int n_rays = (MODE == 0) ? n_hits : n_hits * n_lights;
     const bool robust = sc->robust_filter != 0;
     const int n_groups = sc->n_groups;
+    const float eps = (MODE == 0) ? sc->eps : sc->shadow_eps;
+    const TriExact* __restrict__ exact = sc->tri_exact;
     unsigned long long n_node = 0, n_leaf = 0;
+    unsigned int n_exact = 0;
 
     const unsigned int stride = gridDim.x * blockDim.x;
     const unsigned int n_round = (n_rays + stride - 1) / stride * stride;
     for (unsigned int ray = blockIdx.x * blockDim.x + threadIdx.x; ray < n_round; ray += stride) {
         const bool valid = ray < n_rays;
-        int n_staged = 0;
-        bool bail = false;                              // this ray takes the full reference-precision scan instead
         d3 wpos = mk3(0, 0, 0), wvec = mk3(0, 0, 1);
         int source = -1;
         if (valid) load_world_ray<MODE>(A, sc, ray, n_lights, &wpos, &wvec, &source);
-        for (int g = 0; g < n_groups && valid && !bail; g++) {
-            const Group& G = sc->groups[g];
-            const GroupBvh B = bvh[g];
-            if (B.n <= 0) continue;
-            const GroupFilter fp = G.q[MODE];
-            const float ob = fp.origin_bound, vb = fp.dir_len2_bound;
-            d3 pos = wpos, vec = wvec;
-            if (MODE == 0) to_object_space(sc->xforms + 48 * (size_t)G.xf, G.identity, &pos, &vec);
-            const float px = (float)pos.x, py = (float)pos.y, pz = (float)pos.z;
-            const float vx = (float)vec.x, vy = (float)vec.y, vz = (float)vec.z;
-            const bool trusted = fabsf(px) <= ob && fabsf(py) <= ob && fabsf(pz) <= ob && (vx * vx + vy * vy + vz * vz) <= vb;
-            if (!trusted) { bail = true; break; }
-            const float ix = 1.0f / vx, iy = 1.0f / vy, iz = 1.0f / vz;
-            const int fax1 = G.fax[1], fax2 = G.fax[2];
-            int sp = 0;
-            int cur = (B.n == 1) ? (-1 - B.first_slot) : 0;
-            for (;;) {
+        // per-ray state
+        bool active = valid;                            // still has boxes to visit or triangles staged
+        bool bail = false;                              // this ray takes the full reference-precision scan instead
+        bool need_group = true;                         // the current group is finished (or none was entered yet)
+        int g = -1, cur = 0, sp = 0, n_staged = 0;
+        unsigned long long best = RT_MISS_KEY;          // MODE 0: smallest key found here
+        float t_limit_identity = INFINITY;              // identity groups share the ray's coordinates
+        // per-group context
+        d3 pos = wpos, vec = wvec;
+        float px = 0, py = 0, pz = 0, vx = 0, vy = 0, vz = 1, ix = 0, iy = 0, iz = 1, t_limit = INFINITY;
+        const Group* G = sc->groups;
+        const BvhNode* nodes = nullptr;
+        bool prune = false;
+
+        while (__any(active)) {
+#pragma unroll 1
+            for (int step = 0; step < RT_BVH_STEPS; step++) {
+                if (!active) break;
+                if (need_group) {
+                    if (n_staged > 0) break;            // the staged triangles belong to the group just left: drain first
+                    if (prune) t_limit_identity = t_limit;
+                    int n = 0;
+                    do { g++; n = (g < n_groups) ? bvh[g].n : 0; } while (g < n_groups && n <= 0);
+                    if (g >= n_groups) { active = false; break; }
+                    G = sc->groups + g;
+                    const GroupFilter& Q = G->q[MODE];
+                    prune = (MODE == 0) && G->identity != 0;
+                    pos = wpos; vec = wvec;
+                    if (MODE == 0) to_object_space(sc->xforms + 48 * (size_t)G->xf, G->identity, &pos, &vec);
+                    px = (float)pos.x; py = (float)pos.y; pz = (float)pos.z;
+                    vx = (float)vec.x; vy = (float)vec.y; vz = (float)vec.z;
+                    const float ob = Q.origin_bound;
+                    const bool trusted = fabsf(px) <= ob && fabsf(py) <= ob && fabsf(pz) <= ob &&
+                                         (vx * vx + vy * vy + vz * vz) <= Q.dir_len2_bound;
+                    if (!trusted) { bail = true; active = false; break; }
+                    ix = 1.0f / vx; iy = 1.0f / vy; iz = 1.0f / vz;
+                    t_limit = prune ? t_limit_identity : INFINITY;
+                    nodes = bvh[g].nodes;
+                    cur = (n == 1) ? (-1 - bvh[g].first_slot) : 0;
+                    sp = 0;
+                    need_group = false;
+                    continue;
+                }
                 if (cur < 0) {
-                    // leaf: the FP32 triangle filter, then the pair list
+                    // leaf: the FP32 triangle filter; survivors wait in the stage for the drain phase
+                    if (n_staged == RT_BVH_STAGE) break;
                     const int slot = -1 - cur;
-                    const int axis = slot >= fax2 ? 2 : (slot >= fax1 ? 1 : 0);
+                    const int axis = slot >= G->fax[2] ? 2 : (slot >= G->fax[1] ? 1 : 0);
                     n_leaf++;
-                    if (filter_keep1(filt + 16 * (size_t)slot, axis, px, py, pz, vx, vy, vz, fp.r_lo, fp.a_zero, fp.b_hi, robust,
-                                     MODE)) {
-                        if (n_staged == RT_BVH_STAGE) {
-                            // staging full: this lane appends its entries on its own (rare), then goes on
-                            const unsigned long long base = atomicAdd(A.pair_count, (unsigned long long)RT_BVH_STAGE);
-                            if (base + RT_BVH_STAGE > A.pair_cap) bail = true;
-                            // entries that still fit are written even then: no unwritten slot below pair_cap
-                            for (int k = 0; k < RT_BVH_STAGE && base + k < A.pair_cap; k++)
-                                A.pairs[base + k] = ((unsigned long long)ray << 32) | my_stage[k * RT_BVH_BLOCK];
-                            n_staged = 0;
-                        }
+                    float r_lo;
+                    if (filter_keep1(filt + 16 * (size_t)slot, axis, px, py, pz, vx, vy, vz, G->q[MODE], robust, MODE, &r_lo) &&
+                        !(r_lo > t_limit)) {
                         my_stage[n_staged * RT_BVH_BLOCK] = (unsigned int)slot;
                         n_staged++;
                     }
-                    if (sp == 0 || bail) break;
-                    cur = my_stack[(--sp) * RT_BVH_BLOCK];
+                    if (sp == 0) need_group = true;
+                    else cur = my_stack[(--sp) * RT_BVH_BLOCK];
                     continue;
                 }
-                const BvhNode& N = B.nodes[cur];
+                const BvhNode& N = nodes[cur];
                 n_node += 2;
-                const bool h0 = ray_reaches_box(N.lo[0], N.hi[0], px, py, pz, ix, iy, iz);
-                const bool h1 = ray_reaches_box(N.lo[1], N.hi[1], px, py, pz, ix, iy, iz);
+                float tn0, tn1;
+                const bool h0 = ray_reaches_box(N.lo[0], N.hi[0], px, py, pz, ix, iy, iz, &tn0) && !(tn0 > t_limit);
+                const bool h1 = ray_reaches_box(N.lo[1], N.hi[1], px, py, pz, ix, iy, iz, &tn1) && !(tn1 > t_limit);
                 if (h0 && h1) {
-                    if (sp < RT_BVH_STACK) my_stack[(sp++) * RT_BVH_BLOCK] = N.child[1];
-                    else { bail = true; break; }
-                    cur = N.child[0];
+                    const int near = tn1 < tn0 ? 1 : 0;
+                    if (sp == RT_BVH_STACK) { bail = true; active = false; break; }
+                    my_stack[(sp++) * RT_BVH_BLOCK] = N.child[near ^ 1];
+                    cur = N.child[near];
                 } else if (h0) {
                     cur = N.child[0];
                 } else if (h1) {
                     cur = N.child[1];
+                } else if (sp == 0) {
+                    need_group = true;
                 } else {
-                    if (sp == 0) break;
                     cur = my_stack[(--sp) * RT_BVH_BLOCK];
                 }
             }
+            // drain: reference-precision tests of the staged triangles, all lanes together
+            while (__any(active && n_staged > 0)) {
+                if (active && n_staged > 0) {
+                    const int slot = (int)my_stage[(--n_staged) * RT_BVH_BLOCK];
+                    const TriExact& T = exact[slot];
+                    const float t = tri_intersect_exact(T, pos, vec, eps);
+                    n_exact++;
+                    if (MODE == 0) {
+                        d3 world;
+                        const float d = hit_metric(sc->xforms + 48 * (size_t)G->xf, G->identity, pos, vec, t, &world);
+                        if (t != RT_MISS_T && d < RT_MISS_T) {
+                            const unsigned long long key = make_key(d, T.obj);
+                            if (key < best) best = key;
+                            if (prune) t_limit = fminf(t_limit, t + fabsf(t) * 1e-4f);
+                        }
+                    } else if (t != RT_MISS_T && T.obj != source) {
+                        const unsigned int hit = ray / n_lights, light = ray - hit * n_lights;
+                        atomicOr(&A.occluded[(size_t)hit * A.occl_words + (light >> 5)], 1u << (light & 31));
+                        active = false;                 // occluded: nothing further to find
+                    }
+                }
+            }
         }
-        if (valid && bail) { A.ray_flags[ray] = 1; n_staged = 0; }
-        // append the staged candidates: one atomic per wave
-        int incl = n_staged;
-        for (int off = 1; off < RT_WAVE; off <<= 1) {
-            int up = __shfl_up(incl, off);
-            if (lane >= off) incl += up;
-        }
-        const int total = __shfl(incl, RT_WAVE - 1);
-        if (total > 0) {
-            const unsigned long long base = wave_append(A.pair_count, (unsigned int)total, lane);
-            const unsigned long long first = base + (unsigned int)(incl - n_staged);
-            if (base + (unsigned int)total > A.pair_cap && valid && n_staged > 0) A.ray_flags[ray] = 1;
-            for (int k = 0; k < n_staged && first + k < A.pair_cap; k++)
-                A.pairs[first + k] = ((unsigned long long)ray << 32) | my_stage[k * RT_BVH_BLOCK];
-        }
+        if (valid && bail) A.ray_flags[ray] = 1;
+        if (MODE == 0 && valid && best != RT_MISS_KEY) atomicMin(&A.keys[ray], best);
     }
-    for (int off = 32; off > 0; off >>= 1) { n_node += __shfl_xor(n_node, off); n_leaf += __shfl_xor(n_leaf, off); }
+    for (int off = 32; off > 0; off >>= 1) {
+        n_node += __shfl_xor(n_node, off); n_leaf += __shfl_xor(n_leaf, off); n_exact += __shfl_xor(n_exact, off);
+    }
     if (lane == 0) {
         if (n_node) atomicAdd(&counters->node_tests, n_node);
         if (n_leaf) atomicAdd(&counters->leaf_tests, n_leaf);
+        if (n_exact) atomicAdd(&A.counters->exact_tests, (unsigned long long)n_exact);
     }
 }

@@ -46,7 +46,8 @@ struct GroupFilter {
     float b_hi;            // |n.dir| above this: the reference's grazing branch (raytracer.cpp:319) is not taken
     float origin_bound;    // the thresholds hold for rays with |origin component| <= this
     float dir_len2_bound;  // ... and |dir|^2 <= this; other rays take the reference-precision scan
-    float pad[3];
+    float e_a, e_b;        // error bounds of the FP32 plane distance a and of b = n.dir
+    float r_hi;            // ray parameter at or above this: the reference's r < eps reject is certainly not taken
 };
 
 // Triangles that share one transform.  Filter slots [fax[0], fax[3]) are regular
