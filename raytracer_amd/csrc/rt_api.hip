@@ -134,8 +134,16 @@ struct rt_ctx {
     std::vector<GroupFilter> h_q0, h_q1;  // per transform: nearest-hit / shadow thresholds
     std::vector<int32_t> h_slot;          // per object: slot of its record (spheres: fixed; triangles: per form)
     std::vector<int32_t> h_xf_ident;
+    std::vector<double> h_xf;             // [n_transforms][48]
     int auto_robust = 0;                  // the form chosen from the scene's own numbers
     int robust = 0;                       // the form installed now
+
+    // per-triangle constants shared by all rays of a launch (see filter_keep2)
+    DevBuf<float> eye_a;                  // [n_regular + 1]
+    DevBuf<float> dir_rinv;               // [directional lights][n_regular + 1]
+    DevBuf<int32_t> light_dir_row;        // [n_lights]
+    std::vector<DevLight> h_lights;
+    int shared_consts = 1;                // RT_OPT_SHARED_CONSTANTS
 
     // optional LBVH (RT_OPT_USE_BVH)
     int use_bvh = 0;
@@ -254,8 +262,11 @@ struct Timed {
 
 // Nearest hit (MODE 0) or shadow (MODE 1) of one queue: filter, listed pairs, the rest.
 template <int MODE>
-int launch_trace(rt_ctx* c, TraceArgs A, hipStream_t st) {
+int launch_trace(rt_ctx* c, TraceArgs A, hipStream_t st, bool camera_rays = false) {
     const DevScene* dsc = c->d_scene.p;
+    A.shared_origin_a = (MODE == 0 && camera_rays && c->shared_consts) ? c->eye_a.p : nullptr;
+    A.shared_dir_rinv = (MODE == 1 && c->shared_consts && c->dir_rinv.n > 0) ? c->dir_rinv.p : nullptr;
+    A.light_dir_row = c->light_dir_row.p;
     A.ray_flags = c->ray_flags.p; A.pairs = c->pairs.p; A.pair_count = c->pair_count.p;
     A.task_counter = (unsigned int*)(c->pair_count.p + 1);
     A.pair_cap = (unsigned int)c->pair_cap; A.counters = c->counters.p; A.scan_all = c->force_exact;
@@ -372,7 +383,7 @@ int run_pass(rt_ctx* c, PassDesc pd, int nrows, hipStream_t st) {
         TraceArgs ta{};
         ta.rays = q[cur]; ta.n_items = c->counts.p + k; ta.keys = c->keys[cur].p;
         ta.occl_words = c->occl_words;
-        int rc = launch_trace<0>(c, ta, st);
+        int rc = launch_trace<0>(c, ta, st, k == 0);
         if (rc) return rc;
 
         HitArgs ha{};
@@ -506,6 +517,44 @@ int install_filter(rt_ctx* c, int robust) {
     // a hierarchy built over the previous order is void
     c->bvh_built = false;
     c->bvh_nodes.release(); c->bvh_groups.release();
+
+    // Constants shared by all rays of a launch, in double precision like the reference's own
+    // dot products (raytracer.cpp:316-317): a = -(n . (eye - v1)) for camera rays (the eye in the
+    // group's object space), 1 / (n . dir) for the rays towards each directional light
+    // (world-space direction against the untransformed normal, raytracer.cpp:553).
+    {
+        std::vector<float> eye_a((size_t)NR + 1, 0.f);
+        const Vec eye{c->hs.cam_eye[0], c->hs.cam_eye[1], c->hs.cam_eye[2]};
+        for (const Group& G : groups) {
+            const Vec o = G.identity ? eye : affine_point(&c->h_xf[48 * (size_t)G.xf + 16], eye);
+            for (int k = G.fax[0]; k < G.fax[3]; k++) {
+                const TriExact& ex = exact[k];
+                const Vec w0{o.x - ex.v1[0], o.y - ex.v1[1], o.z - ex.v1[2]};
+                eye_a[k] = (float)(-(ex.n[0] * w0.x + ex.n[1] * w0.y + ex.n[2] * w0.z));
+            }
+        }
+        std::vector<int32_t> row(std::max<size_t>(c->h_lights.size(), 1), -1);
+        std::vector<float> rinv;
+        int n_rows = 0;
+        for (size_t l = 0; l < c->h_lights.size(); l++) {
+            const DevLight& lt = c->h_lights[l];
+            if (lt.is_point) continue;
+            // Light::lightRay: direction = (-pos).normalize() (raytracer.cpp:113-117, algebra3.h:638-662)
+            const double x = -lt.pos[0], y = -lt.pos[1], z = -lt.pos[2];
+            const double len = std::sqrt(x * x + y * y + z * z), inv = 1. / len;
+            const Vec dir{x * inv, y * inv, z * inv};
+            row[l] = n_rows++;
+            rinv.resize((size_t)n_rows * ((size_t)NR + 1), 0.f);
+            float* out = &rinv[(size_t)row[l] * ((size_t)NR + 1)];
+            for (int k = 0; k < NR; k++) {
+                const TriExact& ex = exact[k];
+                out[k] = (float)(1.0 / (ex.n[0] * dir.x + ex.n[1] * dir.y + ex.n[2] * dir.z));
+            }
+        }
+        HIP_TRY(c->eye_a.upload(eye_a));
+        HIP_TRY(c->light_dir_row.upload(row));
+        if (n_rows > 0) HIP_TRY(c->dir_rinv.upload(rinv)); else c->dir_rinv.release();
+    }
 
     HIP_TRY(c->tri_filt.upload(filt)); HIP_TRY(c->tri_exact.upload(exact));
     HIP_TRY(c->groups.upload(groups)); HIP_TRY(c->obj_slot.upload(slot));
@@ -772,6 +821,7 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
         tris.push_back(t);
     }
     c->h_xf_ident = xf_ident;
+    c->h_xf = xf;
     c->scene_bound = R_max;
 
     // ---- which form of the filter: the cheap static margins unless they are useless here ----
@@ -800,6 +850,7 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
     for (int i = 0; i < d->n_materials; i++) std::memcpy(&mats[i], &d->materials[i], sizeof(DevMaterial));
     std::vector<DevLight> lights(d->n_lights);
     for (int i = 0; i < d->n_lights; i++) std::memcpy(&lights[i], &d->lights[i], sizeof(DevLight));
+    c->h_lights = lights;
     static_assert(sizeof(DevMaterial) == sizeof(rt_material), "material layout");
     static_assert(sizeof(DevLight) == sizeof(rt_light), "light layout");
     static_assert(sizeof(TriExact) == 128, "TriExact layout");
@@ -878,6 +929,7 @@ int rt_set_option(rt_ctx* c, int option, int64_t value) {
             if (had_bvh) return build_bvh(c);
             return 0;
         }
+        case RT_OPT_SHARED_CONSTANTS: c->shared_consts = value ? 1 : 0; return 0;
         case RT_OPT_USE_BVH:
             if (value) {
                 int rc = build_bvh(c);
@@ -973,6 +1025,7 @@ void rt_free(rt_ctx* c) {
     c->lvl_obj.release(); c->lvl_phong.release(); c->lvl_child.release(); c->counts.release();
     c->ray_flags.release(); c->pairs.release(); c->pair_count.release();
     c->bvh_nodes.release(); c->bvh_groups.release();
+    c->eye_a.release(); c->dir_rinv.release(); c->light_dir_row.release();
     delete c;
 }
 

@@ -236,7 +236,7 @@ k_bvh_trace(const DevScene* __restrict__ sc, const GroupBvh* __restrict__ bvh, c
         const bool valid = ray < n_rays;
         d3 wpos = mk3(0, 0, 0), wvec = mk3(0, 0, 1);
         int source = -1;
-        if (valid) load_world_ray<MODE>(A, sc, ray, n_lights, &wpos, &wvec, &source);
+        if (valid) load_world_ray<MODE>(A, sc, ray, n_hits, &wpos, &wvec, &source);
         // per-ray state
         bool active = valid;                            // still has boxes to visit or triangles staged
         bool bail = false;                              // this ray takes the full reference-precision scan instead
@@ -332,7 +332,8 @@ k_bvh_trace(const DevScene* __restrict__ sc, const GroupBvh* __restrict__ bvh, c
                             if (prune) t_limit = fminf(t_limit, t + fabsf(t) * 1e-4f);
                         }
                     } else if (t != RT_MISS_T && T.obj != source) {
-                        const unsigned int hit = ray / n_lights, light = ray - hit * n_lights;
+                        unsigned int hit, light;
+                        shadow_ray_index(ray, n_hits, &hit, &light);
                         atomicOr(&A.occluded[(size_t)hit * A.occl_words + (light >> 5)], 1u << (light & 31));
                         active = false;                 // occluded: nothing further to find
                     }

@@ -119,20 +119,33 @@ struct TraceArgs {
     unsigned int* task_counter;          // k_filter: next task to hand out (zeroed before the launch)
     unsigned int pair_cap;
     DevCounters* counters;
+    // Per regular-triangle constants that let k_filter skip work shared by all rays of a launch:
+    const float* shared_origin_a;        // MODE 0, camera rays only (all start at the eye): d0 - n.eye per slot; else null
+    const float* shared_dir_rinv;        // MODE 1: [row][n_regular + 1] of 1 / (n.dir) for directional lights; may be null
+    const int32_t* light_dir_row;        // MODE 1: per light, its row in shared_dir_rinv or -1 (point light)
 };
 
+// Shadow rays are numbered light-major: ray = light * n_hits + hit, so that rays towards one
+// light are neighbours (a block of rays towards a directional light shares its direction).
+__device__ __forceinline__ void shadow_ray_index(unsigned int ray, unsigned int n_hits, unsigned int* hit, unsigned int* light) {
+    const unsigned int l = ray / n_hits;
+    *light = l;
+    *hit = ray - l * n_hits;
+}
+
 // World-space ray number `ray` of a launch.  MODE 0: entry `ray` of the level's queue.
-// MODE 1: shadow ray of hit ray / n_lights towards light ray % n_lights (Light::lightRay,
-// raytracer.cpp:108-119); *source = the object the hit lies on.
+// MODE 1: shadow ray of one hit towards one light (Light::lightRay, raytracer.cpp:108-119);
+// *source = the object the hit lies on.
 template <int MODE>
 __device__ __forceinline__ void load_world_ray(const TraceArgs& A, const DevScene* __restrict__ sc,
-                                               unsigned int ray, unsigned int n_lights, d3* pos, d3* vec, int* source) {
+                                               unsigned int ray, unsigned int n_hits, d3* pos, d3* vec, int* source) {
     if (MODE == 0) {
         *pos = mk3(A.rays.ox[ray], A.rays.oy[ray], A.rays.oz[ray]);
         *vec = mk3(A.rays.dx[ray], A.rays.dy[ray], A.rays.dz[ray]);
         *source = -1;
     } else {
-        const unsigned int hit = ray / n_lights, light = ray - hit * n_lights;
+        unsigned int hit, light;
+        shadow_ray_index(ray, n_hits, &hit, &light);
         *pos = mk3(A.rays.ox[hit], A.rays.oy[hit], A.rays.oz[hit]);
         const DevLight& lt = sc->lights[light];
         d3 lv = lt.is_point ? sub3(ld3(lt.pos), *pos) : neg3(ld3(lt.pos));
@@ -155,7 +168,7 @@ __device__ __forceinline__ void to_object_space(const double* X, int identity, d
 // MODE 1: any hit other than the source (raytracer.cpp:553; a NaN result counts as a hit
 // there because NaN != MAXFLOAT).
 template <int MODE>
-__device__ __forceinline__ void publish_result(const TraceArgs& A, unsigned int ray, unsigned int n_lights, float t,
+__device__ __forceinline__ void publish_result(const TraceArgs& A, unsigned int ray, unsigned int n_hits, float t,
                                                int obj, d3 pos, d3 vec, const double* X, int identity, int source) {
     if (MODE == 0) {
         d3 world;
@@ -163,7 +176,8 @@ __device__ __forceinline__ void publish_result(const TraceArgs& A, unsigned int 
         if (t != RT_MISS_T && d < RT_MISS_T) atomicMin(&A.keys[ray], make_key(d, obj));
     } else {
         if (t != RT_MISS_T && obj != source) {
-            const unsigned int hit = ray / n_lights, light = ray - hit * n_lights;
+            unsigned int hit, light;
+            shadow_ray_index(ray, n_hits, &hit, &light);
             atomicOr(&A.occluded[(size_t)hit * A.occl_words + (light >> 5)], 1u << (light & 31));
         }
     }
@@ -192,20 +206,37 @@ __device__ __forceinline__ void publish_result(const TraceArgs& A, unsigned int 
 // 1/|n.dir| is added per test from f[13 + MODE] (nearest hit / shadow), and the in-plane-origin
 // term also requires a grazing ray, so a ray leaving a flat wall does not list every triangle
 // of that wall.  Two more instructions per ray; chosen per scene when it is uploaded.
+//
+// SHARED: what all rays of the task have in common, with the matching per-triangle constant
+// `shared` computed on the host in double precision (at least as accurate as the FP32
+// evaluation it replaces, so the same margins hold):
+//   1  the origin (camera rays): shared = a = d0 - n.origin, the three multiply-adds go;
+//   2  the direction (shadow rays towards a directional light): shared = 1 / (n.dir), the
+//      three multiply-adds and the reciprocal go.
 struct FilterQuery { float r_lo, a_zero, b_hi; };
 
-template <int MODE, bool ROBUST>
+template <int MODE, bool ROBUST, int SHARED>
 __device__ __forceinline__ void filter_keep2(const v16f f, v2f px, v2f py, v2f pz, v2f vx, v2f vy, v2f vz,
-                                             v2f pu, v2f pv, v2f vu, v2f vv, const FilterQuery Q,
+                                             v2f pu, v2f pv, v2f vu, v2f vv, const FilterQuery Q, const float shared,
                                              bool* keep0, bool* keep1) {
     const v2f n0 = {f[0], f[0]}, n1 = {f[1], f[1]}, n2 = {f[2], f[2]}, d0 = {f[3], f[3]};
-    v2f b = n0 * vx;
-    b = __builtin_elementwise_fma(n1, vy, b);
-    b = __builtin_elementwise_fma(n2, vz, b);
-    v2f a = __builtin_elementwise_fma(-n0, px, d0);
-    a = __builtin_elementwise_fma(-n1, py, a);
-    a = __builtin_elementwise_fma(-n2, pz, a);
-    const v2f rinv = {__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y)};
+    v2f a, b, rinv;
+    if (SHARED == 2) {
+        rinv.x = rinv.y = shared;
+        b.x = b.y = 0.0f;               // not used: the grazing test below reads 1/b
+    } else {
+        b = n0 * vx;
+        b = __builtin_elementwise_fma(n1, vy, b);
+        b = __builtin_elementwise_fma(n2, vz, b);
+        rinv.x = __builtin_amdgcn_rcpf(b.x); rinv.y = __builtin_amdgcn_rcpf(b.y);
+    }
+    if (SHARED == 1) {
+        a.x = a.y = shared;
+    } else {
+        a = __builtin_elementwise_fma(-n0, px, d0);
+        a = __builtin_elementwise_fma(-n1, py, a);
+        a = __builtin_elementwise_fma(-n2, pz, a);
+    }
     const v2f r = a * rinv;
     const v2f hu = __builtin_elementwise_fma(r, vu, pu);
     const v2f hv = __builtin_elementwise_fma(r, vv, pv);
@@ -224,7 +255,11 @@ __device__ __forceinline__ void filter_keep2(const v16f f, v2f px, v2f py, v2f p
     }
     const bool reject0 = (m0 < 0.0f) | (r.x < Q.r_lo);
     const bool reject1 = (m1 < 0.0f) | (r.y < Q.r_lo);
-    if (ROBUST) {
+    if (ROBUST && SHARED == 2) {
+        const bool grazing = !(fabsf(shared) * Q.b_hi < 1.0f);      // |b| <= b_hi, or NaN
+        *keep0 = (!reject0) | ((fabsf(a.x) <= Q.a_zero) & grazing);
+        *keep1 = (!reject1) | ((fabsf(a.y) <= Q.a_zero) & grazing);
+    } else if (ROBUST) {
         *keep0 = (!reject0) | ((fabsf(a.x) <= Q.a_zero) & (fabsf(b.x) <= Q.b_hi));
         *keep1 = (!reject1) | ((fabsf(a.y) <= Q.a_zero) & (fabsf(b.y) <= Q.b_hi));
     } else {
@@ -285,10 +320,12 @@ __device__ __forceinline__ void flush_candidates(const TraceArgs& A, const unsig
 }
 
 // Filter loop over the regular triangles [abeg, aend) whose normals share the dominant axis AXIS.
-template <int MODE, int RPL, int AXIS, bool ROBUST>
-__device__ __forceinline__ void filter_range(const cv16f* filt, const TraceArgs& A, const FilterLane<RPL>& L,
-                                             const FilterQuery fp, int abeg, int aend, unsigned short* my_cand,
-                                             unsigned int ray0, unsigned int n_rays, int lane) {
+typedef __attribute__((address_space(4))) const float cfloat;
+
+template <int MODE, int RPL, int AXIS, bool ROBUST, int SHARED>
+__device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* shared, const TraceArgs& A,
+                                             const FilterLane<RPL>& L, const FilterQuery fp, int abeg, int aend,
+                                             unsigned short* my_cand, unsigned int ray0, unsigned int n_rays, int lane) {
     constexpr int SLOT_SHIFT = RT_SLOT_SHIFT(RPL);
     constexpr int CHUNK = 1 << SLOT_SHIFT;
     v2f pu[RPL / 2], pv[RPL / 2], vu[RPL / 2], vv[RPL / 2];
@@ -305,13 +342,15 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const TraceArgs&
             // The record of triangle j+1 is requested before triangle j is evaluated
             // (the array carries one padding record, so j+1 is always readable).
             v16f cur = filt[j0];
+            float sh_cur = SHARED ? shared[j0] : 0.0f;
             for (int j = j0; j < jn; j++) {
                 const v16f nxt = filt[j + 1];
+                const float sh_nxt = SHARED ? shared[j + 1] : 0.0f;
                 bool keep[RPL], any = false;
 #pragma unroll
                 for (int q = 0; q < RPL / 2; q++) {
-                    filter_keep2<MODE, ROBUST>(cur, L.px[q], L.py[q], L.pz[q], L.vx[q], L.vy[q], L.vz[q], pu[q], pv[q],
-                                               vu[q], vv[q], fp, &keep[2 * q], &keep[2 * q + 1]);
+                    filter_keep2<MODE, ROBUST, SHARED>(cur, L.px[q], L.py[q], L.pz[q], L.vx[q], L.vy[q], L.vz[q], pu[q],
+                                                       pv[q], vu[q], vv[q], fp, sh_cur, &keep[2 * q], &keep[2 * q + 1]);
                     any |= keep[2 * q] | keep[2 * q + 1];
                 }
                 if (any) {               // rarely true for any lane of the wave
@@ -324,6 +363,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const TraceArgs&
                     }
                 }
                 cur = nxt;
+                sh_cur = sh_nxt;
             }
             // Flush when some lane could overflow its staging slots during the next batch,
             // and at the end of the chunk (entries are relative to the chunk base).
@@ -383,6 +423,23 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
         const int part = __builtin_amdgcn_readfirstlane((int)(task / n_ray_blocks));
         const unsigned int rb = task - (unsigned int)part * n_ray_blocks;
         const unsigned int ray0 = rb * RAYS_PER_TASK + lane;          // slot r: ray0 + r * 64
+        // What the task's rays share (see filter_keep2): camera rays their origin; shadow rays
+        // towards one directional light their direction.
+        int shared_kind = 0;
+        const cfloat* shared = nullptr;
+        if (MODE == 0) {
+            if (A.shared_origin_a) { shared_kind = 1; shared = (const cfloat*)A.shared_origin_a; }
+        } else if (A.shared_dir_rinv) {
+            const unsigned int first = rb * RAYS_PER_TASK;
+            const unsigned int last = min(first + RAYS_PER_TASK, n_rays) - 1u;
+            const int l0 = __builtin_amdgcn_readfirstlane((int)(first / n_hits));
+            const int l1 = __builtin_amdgcn_readfirstlane((int)(last / n_hits));
+            const int row = __builtin_amdgcn_readfirstlane(A.light_dir_row[l0]);
+            if (l0 == l1 && row >= 0) {
+                shared_kind = 2;
+                shared = (const cfloat*)(A.shared_dir_rinv + (size_t)row * (size_t)(NR + 1));
+            }
+        }
         bool have_rays = false;
         FilterLane<RPL> L;
 #pragma unroll
@@ -420,7 +477,7 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                     const bool valid = ray < n_rays;
                     d3 pos, vec;
                     int source;
-                    load_world_ray<MODE>(A, sc, valid ? ray : n_rays - 1, n_lights, &pos, &vec, &source);
+                    load_world_ray<MODE>(A, sc, valid ? ray : n_rays - 1, n_hits, &pos, &vec, &source);
                     to_object_space(X, ident, &pos, &vec);
                     float fx = (float)pos.x, fy = (float)pos.y, fz = (float)pos.z;
                     float gx = (float)vec.x, gy = (float)vec.y, gz = (float)vec.z;
@@ -452,9 +509,16 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                 const int abeg = fax[axis] + part * per_part;
                 const int aend = min(fax[axis + 1], abeg + per_part);
                 if (abeg >= aend) continue;
-                if (axis == 0) filter_range<MODE, RPL, 0, ROBUST>(filt, A, L, fp, abeg, aend, my_cand, ray0, n_rays, lane);
-                if (axis == 1) filter_range<MODE, RPL, 1, ROBUST>(filt, A, L, fp, abeg, aend, my_cand, ray0, n_rays, lane);
-                if (axis == 2) filter_range<MODE, RPL, 2, ROBUST>(filt, A, L, fp, abeg, aend, my_cand, ray0, n_rays, lane);
+                constexpr int KIND = (MODE == 0) ? 1 : 2;
+                if (shared_kind == 0) {
+                    if (axis == 0) filter_range<MODE, RPL, 0, ROBUST, 0>(filt, shared, A, L, fp, abeg, aend, my_cand, ray0, n_rays, lane);
+                    if (axis == 1) filter_range<MODE, RPL, 1, ROBUST, 0>(filt, shared, A, L, fp, abeg, aend, my_cand, ray0, n_rays, lane);
+                    if (axis == 2) filter_range<MODE, RPL, 2, ROBUST, 0>(filt, shared, A, L, fp, abeg, aend, my_cand, ray0, n_rays, lane);
+                } else {
+                    if (axis == 0) filter_range<MODE, RPL, 0, ROBUST, KIND>(filt, shared, A, L, fp, abeg, aend, my_cand, ray0, n_rays, lane);
+                    if (axis == 1) filter_range<MODE, RPL, 1, ROBUST, KIND>(filt, shared, A, L, fp, abeg, aend, my_cand, ray0, n_rays, lane);
+                    if (axis == 2) filter_range<MODE, RPL, 2, ROBUST, KIND>(filt, shared, A, L, fp, abeg, aend, my_cand, ray0, n_rays, lane);
+                }
             }
         }
     }
@@ -467,7 +531,8 @@ k_exact_pairs(const DevScene* __restrict__ sc, const TriExact* __restrict__ exac
     const unsigned long long listed = *A.pair_count;
     const unsigned int n = listed < A.pair_cap ? (unsigned int)listed : A.pair_cap;
     const unsigned int n_lights = sc->n_lights;
-    const unsigned int n_rays = (MODE == 0) ? *A.n_items : *A.n_items * n_lights;
+    const unsigned int n_hits = *A.n_items;
+    const unsigned int n_rays = (MODE == 0) ? n_hits : n_hits * n_lights;
     const unsigned int n_regular = (unsigned int)sc->n_regular;
     const float eps = (MODE == 0) ? sc->eps : sc->shadow_eps;
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -486,12 +551,12 @@ k_exact_pairs(const DevScene* __restrict__ sc, const TriExact* __restrict__ exac
         }
         d3 pos, vec;
         int source;
-        load_world_ray<MODE>(A, sc, ray, n_lights, &pos, &vec, &source);
+        load_world_ray<MODE>(A, sc, ray, n_hits, &pos, &vec, &source);
         to_object_space(X, ident, &pos, &vec);
         bool q7 = false;
         const float t = tri_intersect_exact(T, pos, vec, eps, &q7);
         if (q7) atomicAdd(&A.counters->in_plane_origin_hits, 1ull);
-        publish_result<MODE>(A, ray, n_lights, t, T.obj, pos, vec, X, ident, source);
+        publish_result<MODE>(A, ray, n_hits, t, T.obj, pos, vec, X, ident, source);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&A.counters->exact_tests, (unsigned long long)n);
 }
@@ -536,7 +601,7 @@ k_brute(const DevScene* __restrict__ sc, const TriExact* __restrict__ exact, Tra
         if (!any_scan && (part != 0 || NS + NI == 0)) continue;
         d3 wpos = mk3(0, 0, 0), wvec = mk3(0, 0, 1);
         int source = -1;
-        if (valid) load_world_ray<MODE>(A, sc, ray, n_lights, &wpos, &wvec, &source);
+        if (valid) load_world_ray<MODE>(A, sc, ray, n_hits, &wpos, &wvec, &source);
 
         if (part == 0 && valid) {
             for (int s = 0; s < NS; s++) {
@@ -546,7 +611,7 @@ k_brute(const DevScene* __restrict__ sc, const TriExact* __restrict__ exact, Tra
                 const int ident = (MODE == 0) ? S.identity : 1;   // shadow rays are never transformed (raytracer.cpp:553)
                 to_object_space(X, ident, &pos, &vec);
                 const float t = sph_intersect_exact(S, pos, vec, eps);
-                publish_result<MODE>(A, ray, n_lights, t, S.obj, pos, vec, X, ident, source);
+                publish_result<MODE>(A, ray, n_hits, t, S.obj, pos, vec, X, ident, source);
                 n_exact++;
             }
         }
@@ -565,7 +630,7 @@ k_brute(const DevScene* __restrict__ sc, const TriExact* __restrict__ exact, Tra
             if (part == 0 && valid) {
                 for (int i = ibeg; i < iend; i++) {
                     const float t = tri_intersect_exact(exact[i], pos, vec, eps);
-                    publish_result<MODE>(A, ray, n_lights, t, exact[i].obj, pos, vec, X, ident, source);
+                    publish_result<MODE>(A, ray, n_hits, t, exact[i].obj, pos, vec, X, ident, source);
                     n_exact++;
                 }
             }
@@ -586,7 +651,7 @@ k_brute(const DevScene* __restrict__ sc, const TriExact* __restrict__ exact, Tra
                     const int bsource = __shfl(source, src);
                     for (int j = pbeg + lane; j < pend; j += RT_WAVE) {
                         const float t = tri_intersect_exact(exact[j], bpos, bvec, eps);
-                        publish_result<MODE>(A, bray, n_lights, t, exact[j].obj, bpos, bvec, X, ident, bsource);
+                        publish_result<MODE>(A, bray, n_hits, t, exact[j].obj, bpos, bvec, X, ident, bsource);
                         n_exact++;
                     }
                 }
