@@ -2,7 +2,7 @@
 # rocprofv3 kernel trace + stats of the default benchmark command, then the PMC passes.
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-TAG=${1:-r1}
+export TAG=${1:-r1}
 mkdir -p gpurun_out
 timeout -k 10 600 python3 -u bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err || { tail -5 gpurun_out/bench_$TAG.err; exit 1; }
 tail -1 gpurun_out/bench_$TAG.json | cut -c1-400
