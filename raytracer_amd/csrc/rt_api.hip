@@ -150,6 +150,7 @@ struct rt_ctx {
     bool bvh_built = false;
     DevBuf<BvhNode> bvh_nodes;
     DevBuf<GroupBvh> bvh_groups;
+    DevBuf<int> bvh_spill;                // deep traversal-stack entries, one strip per thread of the launch
     std::vector<Group> h_groups;
     std::vector<float> h_centroid_box;   // per group: min[3], max[3] of the triangle centroids
     double scene_bound = 0;
@@ -277,7 +278,7 @@ int launch_trace(rt_ctx* c, TraceArgs A, hipStream_t st, bool camera_rays = fals
         if (c->use_bvh) {
             BvhCounters* bc = (BvhCounters*)&c->counters.p->bvh_node_tests;
             hipLaunchKernelGGL(k_bvh_trace<MODE>, dim3(c->aux_grid), dim3(RT_BVH_BLOCK), 0, st, dsc,
-                               (const GroupBvh*)c->bvh_groups.p, (const float*)c->tri_filt.p, A, bc);
+                               (const GroupBvh*)c->bvh_groups.p, (const float*)c->tri_filt.p, A, bc, c->bvh_spill.p);
         } else {
             if (c->robust)
                 hipLaunchKernelGGL((k_filter<MODE, RT_RPL, true>), dim3(c->filter_grid[MODE]), dim3(RT_BLOCK), 0, st, dsc,
@@ -359,6 +360,7 @@ int build_bvh(rt_ctx* c) {
     }
     release_all();
     HIP_TRY(c->bvh_groups.upload(hb));
+    HIP_TRY(c->bvh_spill.alloc((size_t)c->aux_grid * RT_BVH_BLOCK * RT_BVH_SPILL));
     c->bvh_built = true;
     return 0;
 }
@@ -1024,7 +1026,7 @@ void rt_free(rt_ctx* c) {
     c->aux.release(); c->occluded.release(); c->pixel_of_ray.release(); c->lvl_parent.release();
     c->lvl_obj.release(); c->lvl_phong.release(); c->lvl_child.release(); c->counts.release();
     c->ray_flags.release(); c->pairs.release(); c->pair_count.release();
-    c->bvh_nodes.release(); c->bvh_groups.release();
+    c->bvh_nodes.release(); c->bvh_groups.release(); c->bvh_spill.release();
     c->eye_a.release(); c->dir_rinv.release(); c->light_dir_row.release();
     delete c;
 }

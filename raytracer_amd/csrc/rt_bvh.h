@@ -19,7 +19,8 @@
 #include "rt_kernels.h"
 
 #define RT_BVH_BLOCK 256
-#define RT_BVH_STACK 40         // per-lane traversal stack entries (LDS)
+#define RT_BVH_STACK 24         // per-lane traversal stack entries kept in LDS
+#define RT_BVH_SPILL 48         // ... and deeper ones in a per-thread strip of global memory
 #define RT_BVH_STAGE 4          // per-lane staged candidates (LDS)
 #define RT_BVH_STEPS 8          // traversal steps between two drain phases
 
@@ -214,10 +215,16 @@ __device__ __forceinline__ bool ray_reaches_box(const float* lo, const float* hi
 template <int MODE>
 __global__ void __launch_bounds__(RT_BVH_BLOCK)
 k_bvh_trace(const DevScene* __restrict__ sc, const GroupBvh* __restrict__ bvh, const float* __restrict__ filt,
-            TraceArgs A, BvhCounters* counters) {
+            TraceArgs A, BvhCounters* counters, int* __restrict__ spill) {
     __shared__ int stack[RT_BVH_STACK * RT_BVH_BLOCK];
     __shared__ unsigned int stage[RT_BVH_STAGE * RT_BVH_BLOCK];
     int* my_stack = stack + threadIdx.x;                 // entry k at my_stack[k * RT_BVH_BLOCK]
+    // entries RT_BVH_STACK and deeper: entry k at my_spill[(k - RT_BVH_STACK) * n_threads]
+    const size_t n_threads = (size_t)gridDim.x * RT_BVH_BLOCK;
+    int* my_spill = spill + (size_t)blockIdx.x * RT_BVH_BLOCK + threadIdx.x;
+    auto stack_at = [&](int k) -> int& {
+        return k < RT_BVH_STACK ? my_stack[k * RT_BVH_BLOCK] : my_spill[(size_t)(k - RT_BVH_STACK) * n_threads];
+    };
     unsigned int* my_stage = stage + threadIdx.x;
     const int lane = threadIdx.x & (RT_WAVE - 1);
     const unsigned int n_lights = sc->n_lights;
@@ -293,7 +300,7 @@ k_bvh_trace(const DevScene* __restrict__ sc, const GroupBvh* __restrict__ bvh, c
                         n_staged++;
                     }
                     if (sp == 0) need_group = true;
-                    else cur = my_stack[(--sp) * RT_BVH_BLOCK];
+                    else cur = stack_at(--sp);
                     continue;
                 }
                 const BvhNode& N = nodes[cur];
@@ -303,8 +310,8 @@ k_bvh_trace(const DevScene* __restrict__ sc, const GroupBvh* __restrict__ bvh, c
                 const bool h1 = ray_reaches_box(N.lo[1], N.hi[1], px, py, pz, ix, iy, iz, &tn1) && !(tn1 > t_limit);
                 if (h0 && h1) {
                     const int near = tn1 < tn0 ? 1 : 0;
-                    if (sp == RT_BVH_STACK) { bail = true; active = false; break; }
-                    my_stack[(sp++) * RT_BVH_BLOCK] = N.child[near ^ 1];
+                    if (sp == RT_BVH_STACK + RT_BVH_SPILL) { bail = true; active = false; break; }
+                    stack_at(sp++) = N.child[near ^ 1];
                     cur = N.child[near];
                 } else if (h0) {
                     cur = N.child[0];
@@ -313,7 +320,7 @@ k_bvh_trace(const DevScene* __restrict__ sc, const GroupBvh* __restrict__ bvh, c
                 } else if (sp == 0) {
                     need_group = true;
                 } else {
-                    cur = my_stack[(--sp) * RT_BVH_BLOCK];
+                    cur = stack_at(--sp);
                 }
             }
             // drain: reference-precision tests of the staged triangles, all lanes together
