@@ -14,7 +14,8 @@ resident in HBM before the timed region.  Rank 0 prints one JSON line.
                 on the launch stream, against the 157.3 TFLOP/s FP32 vector peak.
   cpu_baseline  the unmodified reference renderer (oracle/_ref, kind "reference") -- or the
                 C restatement when that binary is absent (kind "port") -- timed on this
-                box's host cores on a 1/8 x 1/8 sub-grid of the same frame.
+                box's host cores on sub-grids of the same frame (16 threads on every 4th pixel,
+                one thread on every 16th).
 """
 import argparse
 import json
@@ -47,29 +48,36 @@ def parse():
 
 
 def cpu_baseline(args, gpu_rays_fn):
-    """Times the reference CPU renderer on a bounded sample of the same workload: the frame
-    at 1/8 x 1/8 resolution, which is exactly every 8th pixel of the full grid in x and y
-    (the camera samples pixel corners: u = x / W)."""
-    w, h = max(1, args.width // 8), max(1, args.height // 8)
-    threads = min(16, os.cpu_count() or 1)
+    """Times the reference CPU renderer on bounded samples of the same workload: the frame at
+    1/k x 1/k resolution is exactly every k-th pixel of the full grid in x and y (the camera
+    samples pixel corners: u = x / W).  Two legs: all the threads this box grants (k = 4) and
+    one thread, the reference as shipped (k = 16)."""
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_render")
-    rays = gpu_rays_fn(w, h)
-    if os.path.exists(ref):
-        out = subprocess.run([ref, args.scene, str(w), str(h), str(args.depth), "-", str(threads)],
-                             check=True, capture_output=True, text=True).stdout
-        secs = json.loads(out.strip().splitlines()[-1])["render_s"]
-        kind = "reference"
-    else:
-        from raytracer_amd import Scene
-        from tests import oracle_api
-        sc = Scene.load(args.scene, w, h, args.depth)
-        t0 = time.perf_counter()
-        oracle_api.Oracle().render(sc, threads=threads)
-        secs = time.perf_counter() - t0
-        kind = "port"
-    return {"value": rays / secs / 1e6, "unit": "Mrays/s", "cores": threads, "kind": kind,
-            "sample": f"{w}x{h} sub-grid (every 8th pixel in x and y) of the {args.width}x{args.height} frame, "
-                      f"{rays} rays, {secs:.2f} s"}
+
+    def leg(k, threads):
+        w, h = max(1, args.width // k), max(1, args.height // k)
+        rays = gpu_rays_fn(w, h)
+        if os.path.exists(ref):
+            out = subprocess.run([ref, args.scene, str(w), str(h), str(args.depth), "-", str(threads)],
+                                 check=True, capture_output=True, text=True).stdout
+            secs = json.loads(out.strip().splitlines()[-1])["render_s"]
+            kind = "reference"
+        else:
+            from raytracer_amd import Scene
+            from tests import oracle_api
+            sc = Scene.load(args.scene, w, h, args.depth)
+            t0 = time.perf_counter()
+            oracle_api.Oracle().render(sc, threads=threads)
+            secs = time.perf_counter() - t0
+            kind = "port"
+        return {"value": rays / secs / 1e6, "unit": "Mrays/s", "cores": threads, "kind": kind,
+                "sample": f"{w}x{h} sub-grid (every {k}th pixel in x and y) of the {args.width}x{args.height} frame, "
+                          f"{rays} rays, {secs:.2f} s"}
+
+    out = leg(4, min(16, os.cpu_count() or 1))
+    one = leg(16, 1)
+    out["single_thread"] = {"value": one["value"], "unit": one["unit"], "sample": one["sample"]}
+    return out
 
 
 def measured_traffic(kernel_label, launches_per_frame):
@@ -214,7 +222,9 @@ def main():
                        "triangles": n_tri, "spheres": n_sph, "lights": scene.desc.n_lights,
                        "tile_rows": args.tile_rows, "parallelism": f"interleaved scanline tiles x{world}",
                        "rays_per_frame": {"primary": n_primary // args.steps, "reflect": n_reflect // args.steps,
-                                          "shadow": n_shadow // args.steps}},
+                                          "shadow": n_shadow // args.steps,
+                                          "note": "traced = reference-equivalent: every ray the reference's traceRay / "
+                                                  "traceShadowRay would be called with, no path pruned"}},
             "roofline": {"bound": "valu_fp32", "kernel": dom, "achieved": achieved / 1e12, "peak": PEAK_FP32_VALU / 1e12,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU,
                          "traffic": measured_traffic(dom, launches / max(1, args.steps)),
@@ -223,7 +233,9 @@ def main():
                          "both_filter_kernels_tflops": both / 1e12,
                          "filter_ms_per_step": both_ms / args.steps,
                          "reference_precision_kernels_ms_per_step": st["exact_ms"] / args.steps,
-                         "exact_retests_per_ray": st["exact_tests"] / max(1, rays_local)},
+                         "exact_retests_per_ray": st["exact_tests"] / max(1, rays_local),
+                         "nominal_tests_per_step": (st["closest_tests"] + st["anyhit_tests"]) / max(1, args.steps),
+                         "executed_reference_precision_tests_per_step": st["exact_tests"] / max(1, args.steps)},
         }
         if lbvh is not None:
             line["lbvh"] = lbvh
