@@ -89,3 +89,36 @@ def test_config5_synthetic_small(oracle):
     assert_parity(img, want, max_diff_pixels=6)
     for key in ("rays_reflect", "rays_shadow", "hits"):
         assert st[key] == c[key], key
+
+
+def test_config5_million_triangles_8k_through_the_lbvh(oracle, tmp_path):
+    """The stress configuration at its full size: 1,000,000 triangles + 64 spheres, 16 lights,
+    depth 8, 7680 x 4320.  Brute force would take minutes per frame; the LBVH path renders the
+    whole frame, and (a) its sub-grid equals the CPU oracle's small frame, (b) at a small size
+    the LBVH frame equals the brute-force frame byte for byte."""
+    import subprocess
+    import sys
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synthetic.py"), str(tmp_path)], check=True)
+    path = os.path.join(str(tmp_path), "synthetic.scene")
+    from raytracer_amd.render import Renderer
+
+    def render(w, h, bvh):
+        r = Renderer(Scene.load(path, w, h, 8))
+        if bvh:
+            r.set_option(abi.RT_OPT_USE_BVH, 1)
+        r.render_frame()
+        img, st = r.download(), r.stats()
+        r.close()
+        return img, st
+
+    k = 240
+    big, st = render(7680, 4320, True)
+    assert st["n_triangles"] == 1000000 and st["n_spheres"] == 64 and st["rays_primary"] == 7680 * 4320
+    assert st["flagged_rays"] == 0
+    want, _ = oracle.render(Scene.load(path, 7680 // k, 4320 // k, 8), threads=16)
+    assert_parity(subgrid(big, k), want)
+    a, sa = render(256, 144, True)
+    b, sb = render(256, 144, False)
+    assert np.array_equal(a, b)
+    for key in ("rays_reflect", "rays_shadow", "hits"):
+        assert sa[key] == sb[key], key
