@@ -276,9 +276,11 @@ int launch_trace(rt_ctx* c, TraceArgs A, hipStream_t st, bool camera_rays = fals
     if (!c->force_exact && c->hs.n_regular > 0) {
         Timed t(c, st, MODE);
         if (c->use_bvh) {
-            BvhCounters* bc = (BvhCounters*)&c->counters.p->bvh_node_tests;
-            hipLaunchKernelGGL(k_bvh_trace<MODE>, dim3(c->aux_grid), dim3(RT_BVH_BLOCK), 0, st, dsc,
-                               (const GroupBvh*)c->bvh_groups.p, (const float*)c->tri_filt.p, A, bc, c->bvh_spill.p);
+            BvhArgs ba;
+            ba.bvh = c->bvh_groups.p; ba.nodes = c->bvh_nodes.p; ba.filt = (const float*)c->tri_filt.p;
+            ba.exact = c->tri_exact.p; ba.groups = c->groups.p; ba.xforms = c->xforms.p;
+            ba.spill = c->bvh_spill.p; ba.counters = (BvhCounters*)&c->counters.p->bvh_node_tests;
+            hipLaunchKernelGGL(k_bvh_trace<MODE>, dim3(c->aux_grid), dim3(RT_BVH_BLOCK), 0, st, dsc, ba, A);
         } else {
             if (c->robust)
                 hipLaunchKernelGGL((k_filter<MODE, RT_RPL, true>), dim3(c->filter_grid[MODE]), dim3(RT_BLOCK), 0, st, dsc,
@@ -330,7 +332,7 @@ int build_bvh(rt_ctx* c) {
     for (size_t g = 0; g < G; g++) {
         const Group& Gr = c->h_groups[g];
         const int base = Gr.fax[0], n = Gr.fax[3] - Gr.fax[0];
-        hb[g].nodes = c->bvh_nodes.p + node_off;
+        hb[g].node_offset = node_off;
         hb[g].n = n;
         hb[g].first_slot = base;
         if (n <= 1) continue;

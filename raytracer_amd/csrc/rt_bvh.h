@@ -31,7 +31,7 @@ struct __attribute__((aligned(16))) BvhNode {
 };
 
 struct GroupBvh {
-    const BvhNode* nodes;       // n - 1 internal nodes, root = node 0
+    unsigned long long node_offset;   // the group's n - 1 internal nodes start here in the node array; root first
     int32_t n;                  // triangles in the group
     int32_t first_slot;         // n == 1: the only triangle's slot
 };
@@ -212,18 +212,38 @@ __device__ __forceinline__ bool ray_reaches_box(const float* lo, const float* hi
 //   shadow ray: the first accepted hit off the source object settles it (raytracer.cpp:553).
 // Results are merged exactly as k_exact_pairs does (atomicMin of the key / atomicOr of the
 // light's bit), so the other kernels of the launch need not know which path produced them.
+// Every array the traversal reads is a kernel argument (not a pointer fetched from the scene
+// header), so that the loads are global-memory loads rather than generic ones.
+struct BvhArgs {
+    const GroupBvh* bvh;            // per group
+    const BvhNode* nodes;           // all groups' nodes; GroupBvh::node_offset indexes into it
+    const float* filt;              // FP32 filter records, 16 floats per regular triangle
+    const TriExact* exact;
+    const Group* groups;
+    const double* xforms;
+    int* spill;                     // deep stack entries: [RT_BVH_SPILL][threads of the launch]
+    BvhCounters* counters;
+};
+
 template <int MODE>
 __global__ void __launch_bounds__(RT_BVH_BLOCK)
-k_bvh_trace(const DevScene* __restrict__ sc, const GroupBvh* __restrict__ bvh, const float* __restrict__ filt,
-            TraceArgs A, BvhCounters* counters, int* __restrict__ spill) {
+k_bvh_trace(const DevScene* __restrict__ sc, BvhArgs B, TraceArgs A) {
+    const GroupBvh* __restrict__ bvh = B.bvh;
+    const float* __restrict__ filt = B.filt;
+    BvhCounters* counters = B.counters;
+    int* __restrict__ spill = B.spill;
     __shared__ int stack[RT_BVH_STACK * RT_BVH_BLOCK];
     __shared__ unsigned int stage[RT_BVH_STAGE * RT_BVH_BLOCK];
     int* my_stack = stack + threadIdx.x;                 // entry k at my_stack[k * RT_BVH_BLOCK]
     // entries RT_BVH_STACK and deeper: entry k at my_spill[(k - RT_BVH_STACK) * n_threads]
     const size_t n_threads = (size_t)gridDim.x * RT_BVH_BLOCK;
     int* my_spill = spill + (size_t)blockIdx.x * RT_BVH_BLOCK + threadIdx.x;
-    auto stack_at = [&](int k) -> int& {
+    auto stack_get = [&](int k) -> int {
         return k < RT_BVH_STACK ? my_stack[k * RT_BVH_BLOCK] : my_spill[(size_t)(k - RT_BVH_STACK) * n_threads];
+    };
+    auto stack_put = [&](int k, int v) {
+        if (k < RT_BVH_STACK) my_stack[k * RT_BVH_BLOCK] = v;
+        else my_spill[(size_t)(k - RT_BVH_STACK) * n_threads] = v;
     };
     unsigned int* my_stage = stage + threadIdx.x;
     const int lane = threadIdx.x & (RT_WAVE - 1);
@@ -233,7 +253,7 @@ k_bvh_trace(const DevScene* __restrict__ sc, const GroupBvh* __restrict__ bvh, c
     const bool robust = sc->robust_filter != 0;
     const int n_groups = sc->n_groups;
     const float eps = (MODE == 0) ? sc->eps : sc->shadow_eps;
-    const TriExact* __restrict__ exact = sc->tri_exact;
+    const TriExact* __restrict__ exact = B.exact;
     unsigned long long n_node = 0, n_leaf = 0;
     unsigned int n_exact = 0;
 
@@ -254,7 +274,7 @@ k_bvh_trace(const DevScene* __restrict__ sc, const GroupBvh* __restrict__ bvh, c
         // per-group context
         d3 pos = wpos, vec = wvec;
         float px = 0, py = 0, pz = 0, vx = 0, vy = 0, vz = 1, ix = 0, iy = 0, iz = 1, t_limit = INFINITY;
-        const Group* G = sc->groups;
+        const Group* G = B.groups;
         const BvhNode* nodes = nullptr;
         bool prune = false;
 
@@ -268,11 +288,11 @@ k_bvh_trace(const DevScene* __restrict__ sc, const GroupBvh* __restrict__ bvh, c
                     int n = 0;
                     do { g++; n = (g < n_groups) ? bvh[g].n : 0; } while (g < n_groups && n <= 0);
                     if (g >= n_groups) { active = false; break; }
-                    G = sc->groups + g;
+                    G = B.groups + g;
                     const GroupFilter& Q = G->q[MODE];
                     prune = (MODE == 0) && G->identity != 0;
                     pos = wpos; vec = wvec;
-                    if (MODE == 0) to_object_space(sc->xforms + 48 * (size_t)G->xf, G->identity, &pos, &vec);
+                    if (MODE == 0) to_object_space(B.xforms + 48 * (size_t)G->xf, G->identity, &pos, &vec);
                     px = (float)pos.x; py = (float)pos.y; pz = (float)pos.z;
                     vx = (float)vec.x; vy = (float)vec.y; vz = (float)vec.z;
                     const float ob = Q.origin_bound;
@@ -281,7 +301,7 @@ k_bvh_trace(const DevScene* __restrict__ sc, const GroupBvh* __restrict__ bvh, c
                     if (!trusted) { bail = true; active = false; break; }
                     ix = 1.0f / vx; iy = 1.0f / vy; iz = 1.0f / vz;
                     t_limit = prune ? t_limit_identity : INFINITY;
-                    nodes = bvh[g].nodes;
+                    nodes = B.nodes + bvh[g].node_offset;
                     cur = (n == 1) ? (-1 - bvh[g].first_slot) : 0;
                     sp = 0;
                     need_group = false;
@@ -300,7 +320,7 @@ k_bvh_trace(const DevScene* __restrict__ sc, const GroupBvh* __restrict__ bvh, c
                         n_staged++;
                     }
                     if (sp == 0) need_group = true;
-                    else cur = stack_at(--sp);
+                    else cur = stack_get(--sp);
                     continue;
                 }
                 const BvhNode& N = nodes[cur];
@@ -311,7 +331,7 @@ k_bvh_trace(const DevScene* __restrict__ sc, const GroupBvh* __restrict__ bvh, c
                 if (h0 && h1) {
                     const int near = tn1 < tn0 ? 1 : 0;
                     if (sp == RT_BVH_STACK + RT_BVH_SPILL) { bail = true; active = false; break; }
-                    stack_at(sp++) = N.child[near ^ 1];
+                    stack_put(sp++, N.child[near ^ 1]);
                     cur = N.child[near];
                 } else if (h0) {
                     cur = N.child[0];
@@ -320,7 +340,7 @@ k_bvh_trace(const DevScene* __restrict__ sc, const GroupBvh* __restrict__ bvh, c
                 } else if (sp == 0) {
                     need_group = true;
                 } else {
-                    cur = stack_at(--sp);
+                    cur = stack_get(--sp);
                 }
             }
             // drain: reference-precision tests of the staged triangles, all lanes together
@@ -332,7 +352,7 @@ k_bvh_trace(const DevScene* __restrict__ sc, const GroupBvh* __restrict__ bvh, c
                     n_exact++;
                     if (MODE == 0) {
                         d3 world;
-                        const float d = hit_metric(sc->xforms + 48 * (size_t)G->xf, G->identity, pos, vec, t, &world);
+                        const float d = hit_metric(B.xforms + 48 * (size_t)G->xf, G->identity, pos, vec, t, &world);
                         if (t != RT_MISS_T && d < RT_MISS_T) {
                             const unsigned long long key = make_key(d, T.obj);
                             if (key < best) best = key;
