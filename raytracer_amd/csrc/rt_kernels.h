@@ -268,6 +268,82 @@ __device__ __forceinline__ void filter_keep2(const v16f f, v2f px, v2f py, v2f p
     }
 }
 
+// The same test in the form the scan loop uses: per ray ONE number z = min(s, t, u, r - r_lo)
+// (z >= 0: not rejected), so that the wave can ask "does any of my 8 rays keep this triangle?"
+// with a maximum over the z's and a single comparison, instead of three comparisons per ray
+// whose results have to be merged on the scalar unit.  A NaN z (0 * inf: origin on the plane AND
+// direction in it) drops out of that maximum; such a pair is kept by the in-plane-origin
+// term, for which *a_min collects the smallest |a| of the lane's rays.
+template <int MODE, bool ROBUST, int SHARED>
+__device__ __forceinline__ void filter_z2(const v16f f, v2f px, v2f py, v2f pz, v2f vx, v2f vy, v2f vz,
+                                          v2f pu, v2f pv, v2f vu, v2f vv, const FilterQuery Q, const float shared,
+                                          float* z0, float* z1, float* a_min) {
+    const v2f n0 = {f[0], f[0]}, n1 = {f[1], f[1]}, n2 = {f[2], f[2]}, d0 = {f[3], f[3]};
+    v2f a, rinv;
+    if (SHARED == 2) {
+        rinv.x = rinv.y = shared;
+    } else {
+        v2f b = n0 * vx;
+        b = __builtin_elementwise_fma(n1, vy, b);
+        b = __builtin_elementwise_fma(n2, vz, b);
+        rinv.x = __builtin_amdgcn_rcpf(b.x); rinv.y = __builtin_amdgcn_rcpf(b.y);
+    }
+    if (SHARED == 1) {
+        a.x = a.y = shared;
+    } else {
+        a = __builtin_elementwise_fma(-n0, px, d0);
+        a = __builtin_elementwise_fma(-n1, py, a);
+        a = __builtin_elementwise_fma(-n2, pz, a);
+        *a_min = __builtin_fminf(__builtin_fminf(*a_min, fabsf(a.x)), fabsf(a.y));
+    }
+    const v2f r = a * rinv;
+    const v2f hu = __builtin_elementwise_fma(r, vu, pu);
+    const v2f hv = __builtin_elementwise_fma(r, vv, pv);
+    const v2f c4 = {f[4], f[4]}, c5 = {f[5], f[5]}, c6 = {f[6], f[6]};
+    const v2f c7 = {f[7], f[7]}, c8 = {f[8], f[8]}, c9 = {f[9], f[9]};
+    const v2f c10 = {f[10], f[10]}, c11 = {f[11], f[11]}, c12 = {f[12], f[12]};
+    const v2f s = __builtin_elementwise_fma(c4, hu, __builtin_elementwise_fma(c5, hv, c6));
+    const v2f t = __builtin_elementwise_fma(c7, hu, __builtin_elementwise_fma(c8, hv, c9));
+    const v2f u = __builtin_elementwise_fma(c10, hu, __builtin_elementwise_fma(c11, hv, c12));
+    const v2f rlo2 = {Q.r_lo, Q.r_lo};
+    const v2f w = r - rlo2;
+    float m0 = __builtin_fminf(__builtin_fminf(s.x, t.x), u.x);
+    float m1 = __builtin_fminf(__builtin_fminf(s.y, t.y), u.y);
+    if (ROBUST) {
+        const float gm = f[13 + MODE];
+        m0 = __builtin_fmaf(gm, fabsf(rinv.x), m0);
+        m1 = __builtin_fmaf(gm, fabsf(rinv.y), m1);
+    }
+    *z0 = __builtin_fminf(m0, w.x);
+    *z1 = __builtin_fminf(m1, w.y);
+}
+
+// The in-plane-origin term of the test for two rays (rare path; recomputes a and b).
+template <bool ROBUST, int SHARED>
+__device__ __forceinline__ void filter_in_plane2(const v16f f, v2f px, v2f py, v2f pz, v2f vx, v2f vy, v2f vz,
+                                                 const FilterQuery Q, const float shared, bool* k0, bool* k1) {
+    const v2f n0 = {f[0], f[0]}, n1 = {f[1], f[1]}, n2 = {f[2], f[2]}, d0 = {f[3], f[3]};
+    v2f a;
+    if (SHARED == 1) {
+        a.x = a.y = shared;
+    } else {
+        a = __builtin_elementwise_fma(-n0, px, d0);
+        a = __builtin_elementwise_fma(-n1, py, a);
+        a = __builtin_elementwise_fma(-n2, pz, a);
+    }
+    bool g0 = true, g1 = true;
+    if (ROBUST && SHARED == 2) {
+        g0 = g1 = !(fabsf(shared) * Q.b_hi < 1.0f);                 // |b| <= b_hi, or NaN
+    } else if (ROBUST) {
+        v2f b = n0 * vx;
+        b = __builtin_elementwise_fma(n1, vy, b);
+        b = __builtin_elementwise_fma(n2, vz, b);
+        g0 = fabsf(b.x) <= Q.b_hi; g1 = fabsf(b.y) <= Q.b_hi;
+    }
+    *k0 = (fabsf(a.x) <= Q.a_zero) & g0;
+    *k1 = (fabsf(a.y) <= Q.a_zero) & g1;
+}
+
 template <int RPL> struct FilterLane {     // ray slots 2q and 2q+1 share a float2
     v2f px[RPL / 2], py[RPL / 2], pz[RPL / 2], vx[RPL / 2], vy[RPL / 2], vz[RPL / 2];
     unsigned int on;     // bit r: candidates of slot r count (the slot holds a ray the filter may judge)
@@ -346,14 +422,36 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
             for (int j = j0; j < jn; j++) {
                 const v16f nxt = filt[j + 1];
                 const float sh_nxt = SHARED ? shared[j + 1] : 0.0f;
-                bool keep[RPL], any = false;
+                float z[RPL], z_max = -INFINITY, a_min = INFINITY;
 #pragma unroll
                 for (int q = 0; q < RPL / 2; q++) {
-                    filter_keep2<MODE, ROBUST, SHARED>(cur, L.px[q], L.py[q], L.pz[q], L.vx[q], L.vy[q], L.vz[q], pu[q],
-                                                       pv[q], vu[q], vv[q], fp, sh_cur, &keep[2 * q], &keep[2 * q + 1]);
-                    any |= keep[2 * q] | keep[2 * q + 1];
+                    filter_z2<MODE, ROBUST, SHARED>(cur, L.px[q], L.py[q], L.pz[q], L.vx[q], L.vy[q], L.vz[q], pu[q], pv[q],
+                                                    vu[q], vv[q], fp, sh_cur, &z[2 * q], &z[2 * q + 1], &a_min);
+                    z_max = __builtin_fmaxf(__builtin_fmaxf(z_max, z[2 * q]), z[2 * q + 1]);
                 }
-                if (any) {               // rarely true for any lane of the wave
+                if (SHARED == 1) a_min = fabsf(sh_cur);
+                const bool maybe_in_plane = a_min <= fp.a_zero;
+                if ((z_max >= 0.0f) | maybe_in_plane) {               // rarely true for any lane of the wave
+                    // (The empty asm statements pin this block's arithmetic inside the branch: the
+                    // compiler would otherwise hoist it into the loop body that every triangle pays for.)
+                    bool keep[RPL];
+#pragma unroll
+                    for (int r = 0; r < RPL; r++) {
+                        float zr = z[r];
+                        asm volatile("" : "+v"(zr));
+                        keep[r] = zr >= 0.0f;
+                    }
+                    if (maybe_in_plane) {
+#pragma unroll
+                        for (int q = 0; q < RPL / 2; q++) {
+                            bool k0, k1;
+                            v2f pxq = L.px[q], vxq = L.vx[q];
+                            asm volatile("" : "+v"(pxq), "+v"(vxq));
+                            filter_in_plane2<ROBUST, SHARED>(cur, pxq, L.py[q], L.pz[q], vxq, L.vy[q], L.vz[q], fp, sh_cur,
+                                                             &k0, &k1);
+                            keep[2 * q] |= k0; keep[2 * q + 1] |= k1;
+                        }
+                    }
 #pragma unroll
                     for (int r = 0; r < RPL; r++) {
                         if (keep[r] && ((L.on >> r) & 1u)) {
