@@ -205,9 +205,8 @@ def main():
         achieved = tests * flop_per_test / (ms * 1e-3) if ms > 0 else 0.0
         both_ms = st["closest_ms"] + st["anyhit_ms"]
         both = (st["closest_tests"] + st["anyhit_tests"]) * flop_per_test / (both_ms * 1e-3) if both_ms > 0 else 0.0
-        props = torch.cuda.get_device_properties(dev)
-        clock_khz = getattr(props, "clock_rate", None)
-        device_peak = (props.multi_processor_count * 128 * 2 * clock_khz * 1e3) if clock_khz else None
+        n_cu, clock_khz = r.device_info()
+        device_peak = (n_cu * 128 * 2 * clock_khz * 1e3) if clock_khz else None
         line = {
             "metric": "Mrays/s (primary+shadow+reflect) teapot 4K depth-5",
             "value": rays_total / elapsed / 1e6,
@@ -230,7 +229,7 @@ def main():
                                                   "traceShadowRay would be called with, no path pruned"}},
             "roofline": {"bound": "valu_fp32", "kernel": dom, "achieved": achieved / 1e12, "peak": PEAK_FP32_VALU / 1e12,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU,
-                         "peak_from_device_properties": {"compute_units": props.multi_processor_count,
+                         "peak_from_device_properties": {"compute_units": n_cu,
                                                          "clock_mhz": clock_khz / 1e3 if clock_khz else None,
                                                          "tflops": device_peak / 1e12 if device_peak else None},
                          "traffic": measured_traffic(dom, launches / max(1, args.steps)),

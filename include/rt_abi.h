@@ -159,6 +159,11 @@ int rt_download(rt_ctx* ctx, uint8_t* rgba, size_t bytes);
 int rt_get_stats(rt_ctx* ctx, rt_stats* out);   /* waits for the ctx's work */
 int rt_reset_stats(rt_ctx* ctx);
 
+/* The device the ctx lives on: number of compute units and the engine clock in kHz as the HIP
+ * runtime reports them (the measurement harness derives the FP32 vector peak from these:
+ * CUs x 128 lanes x 2 x clock).  No counterpart in the reference. */
+int rt_device_info(rt_ctx* ctx, int32_t* compute_units, int32_t* clock_khz);
+
 void rt_free(rt_ctx* ctx);
 
 const char* rt_last_error(void);

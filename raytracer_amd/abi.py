@@ -63,8 +63,8 @@ class RtStats(C.Structure):
 HOST_SYMBOLS = ["rth_load_scene", "rth_load_blob", "rth_save_blob", "rth_desc", "rth_free_scene",
                 "rth_write_png", "rth_last_error"]
 DEVICE_SYMBOLS = ["rt_upload_scene", "rt_set_option", "rt_render_tile", "rt_render_tiles",
-                  "rt_bind_frame", "rt_download", "rt_get_stats", "rt_reset_stats", "rt_free",
-                  "rt_last_error"]
+                  "rt_bind_frame", "rt_download", "rt_get_stats", "rt_reset_stats", "rt_device_info",
+                  "rt_free", "rt_last_error"]
 
 _host = None
 _device = None
@@ -125,6 +125,8 @@ def device_lib():
         lib.rt_get_stats.restype = C.c_int
         lib.rt_reset_stats.argtypes = [C.c_void_p]
         lib.rt_reset_stats.restype = C.c_int
+        lib.rt_device_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        lib.rt_device_info.restype = C.c_int
         lib.rt_free.argtypes = [C.c_void_p]
         lib.rt_free.restype = None
         lib.rt_last_error.argtypes = []

@@ -135,6 +135,7 @@ struct rt_ctx {
     std::vector<int32_t> h_slot;          // per object: slot of its record (spheres: fixed; triangles: per form)
     std::vector<int32_t> h_xf_ident;
     std::vector<double> h_xf;             // [n_transforms][48]
+    int clock_khz = 0;                    // engine clock reported by the runtime
     int auto_robust = 0;                  // the form chosen from the scene's own numbers
     int robust = 0;                       // the form installed now
 
@@ -610,6 +611,7 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
     if (hipGetDevice(&c->device) != hipSuccess || hipGetDeviceProperties(&prop, c->device) != hipSuccess)
         return bail(fail(RT_ERR_DEVICE, "rt_upload_scene: cannot query the current device"));
     c->n_cu = prop.multiProcessorCount;
+    c->clock_khz = prop.clockRate;
 
     const int NX = d->n_transforms;
     // ---- transforms ----
@@ -1010,6 +1012,13 @@ int rt_reset_stats(rt_ctx* c) {
     drain_spans(c);
     for (int k = 0; k < 3; k++) { c->ms[k] = 0; c->launches[k] = 0; }
     HIP_TRY(hipMemset(c->counters.p, 0, sizeof(DevCounters)));
+    return 0;
+}
+
+int rt_device_info(rt_ctx* c, int32_t* compute_units, int32_t* clock_khz) {
+    if (!c) return fail(RT_ERR_ARG, "rt_device_info: null ctx");
+    if (compute_units) *compute_units = c->n_cu;
+    if (clock_khz) *clock_khz = c->clock_khz;
     return 0;
 }
 

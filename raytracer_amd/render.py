@@ -70,6 +70,12 @@ class Renderer:
         _check(self._lib, self._lib.rt_get_stats(self._ctx, C.byref(st)), "rt_get_stats")
         return st.as_dict()
 
+    def device_info(self):
+        """(compute units, engine clock in kHz) of the device this renderer lives on."""
+        cu, khz = C.c_int32(), C.c_int32()
+        _check(self._lib, self._lib.rt_device_info(self._ctx, C.byref(cu), C.byref(khz)), "rt_device_info")
+        return cu.value, khz.value
+
     def reset_stats(self):
         _check(self._lib, self._lib.rt_reset_stats(self._ctx), "rt_reset_stats")
 
