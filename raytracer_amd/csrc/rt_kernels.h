@@ -503,7 +503,7 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
     // Tasks = (block of 64*RPL rays) x (part of the triangle range), handed out through a
     // global counter.  Enough parts that every wave gets several tasks: short tasks keep the
     // chip full until the end of the launch.
-    int max_split = (NR + 511) / 512;
+    int max_split = (NR + 127) / 128;
     int split = 1;
     if (n_ray_blocks < 8u * n_waves) {
         split = (int)((8u * n_waves + n_ray_blocks - 1) / n_ray_blocks);
