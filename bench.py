@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exact-only", action="store_true")
     ap.add_argument("--no-lbvh", action="store_true", help="skip the extra LBVH-mode measurement")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="one stream: no overlap of a level's shadow launches with the next level's nearest-hit launches")
     return ap.parse_args()
 
 
@@ -139,17 +141,32 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if args.no_overlap:
+        r.set_option(abi.RT_OPT_OVERLAP, 0)
     for _ in range(args.warmup):
         step()
     fence()
     r.reset_stats()
-    r.set_option(abi.RT_OPT_PROFILE, 1)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    st_timed = r.stats()
+
+    # Kernel durations for the roofline: the same K frames once more with HIP events around every
+    # trace-kernel launch (recorded by the library on the launch stream).  Event timing serialises
+    # the library's two streams, so that a kernel's duration is its own and not that of two
+    # kernels sharing the chip; the headline above is measured without it.
+    r.reset_stats()
+    r.set_option(abi.RT_OPT_PROFILE, 1)
+    fence()
+    tp = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    serial_elapsed = time.perf_counter() - tp
     st = r.stats()
     r.set_option(abi.RT_OPT_PROFILE, 0)
 
@@ -183,17 +200,18 @@ def main():
                 "exact_retests_per_ray": sb["exact_tests"] / max(1, lb_rays),
                 "note": "frames byte-identical to brute force (tests/test_gpu_bvh.py)"}
 
-    rays_local = st["rays_primary"] + st["rays_reflect"] + st["rays_shadow"]
+    rays_local = st_timed["rays_primary"] + st_timed["rays_reflect"] + st_timed["rays_shadow"]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        cnt = torch.tensor([rays_local, st["rays_primary"], st["rays_reflect"], st["rays_shadow"]],
+        cnt = torch.tensor([rays_local, st_timed["rays_primary"], st_timed["rays_reflect"], st_timed["rays_shadow"]],
                            dtype=torch.int64, device=dev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         rays_total, n_primary, n_reflect, n_shadow = [int(v) for v in cnt.tolist()]
     else:
-        rays_total, n_primary, n_reflect, n_shadow = rays_local, st["rays_primary"], st["rays_reflect"], st["rays_shadow"]
+        rays_total, n_primary, n_reflect, n_shadow = (rays_local, st_timed["rays_primary"], st_timed["rays_reflect"],
+                                                      st_timed["rays_shadow"])
 
     if rank == 0:
         n_tri, n_sph = st["n_triangles"], st["n_spheres"]
@@ -221,6 +239,7 @@ def main():
             "dtype": "f32 filter + f64/f32 reference-precision re-test",
             "data": "synthetic (teapot.obj mesh + 2 floor triangles, authored scene file)",
             "config": {"workload": f"{os.path.basename(args.scene)} {args.width}x{args.height} depth {args.depth}",
+                       "streams": "one" if args.no_overlap else "two (shadow launches beside the next level's nearest-hit launches)",
                        "triangles": n_tri, "spheres": n_sph, "lights": scene.desc.n_lights,
                        "tile_rows": args.tile_rows, "parallelism": f"interleaved scanline tiles x{world}",
                        "rays_per_frame": {"primary": n_primary // args.steps, "reflect": n_reflect // args.steps,
@@ -234,6 +253,10 @@ def main():
                                                          "tflops": device_peak / 1e12 if device_peak else None},
                          "traffic": measured_traffic(dom, launches / max(1, args.steps)),
                          "kernel_ms_avg": ms / max(1, launches), "launches": launches,
+                         "timing": "HIP events on the launch stream, K frames after the timed region with the "
+                                   "library's two streams serialised (%.2f ms per frame that way)" % (serial_elapsed / args.steps * 1e3),
+                         "whole_frame_tflops_in_timed_region": (st["closest_tests"] + st["anyhit_tests"]) * flop_per_test
+                                                               / args.steps / (elapsed / args.steps) / 1e12,
                          "flop_per_test": flop_per_test, "tests_per_launch": tests / max(1, launches),
                          "both_filter_kernels_tflops": both / 1e12,
                          "filter_ms_per_step": both_ms / args.steps,

@@ -95,9 +95,12 @@ typedef enum rt_option {
                                 margins (two more instructions per test; for meshes of triangles that are
                                 tiny against the scene, or with many triangles in one plane).  Frames are
                                 identical in every form; blocks until queued work has finished */
-    RT_OPT_SHARED_CONSTANTS = 6 /* 1 (default): the brute-force filter reads host-computed per-triangle constants
+    RT_OPT_SHARED_CONSTANTS = 6, /* 1 (default): the brute-force filter reads host-computed per-triangle constants
                                 where all rays of a launch share their origin (camera rays) or their direction
                                 (shadow rays towards a directional light); 0: every ray is treated alike */
+    RT_OPT_OVERLAP = 7       /* 1 (default): a level's shadow-ray launches run on an internal stream beside the
+                                next level's nearest-hit launches (joined back into the caller's stream before
+                                the call's last kernel); 0: one stream.  Off while RT_OPT_PROFILE is on */
 } rt_option;
 
 /* Counters since rt_upload_scene or the last rt_reset_stats. */

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 RT_OK, RT_ERR_ARG, RT_ERR_DEVICE, RT_ERR_RANGE, RT_ERR_STATE = 0, -1, -2, -3, -4
-RT_OPT_EXACT_ONLY, RT_OPT_PROFILE, RT_OPT_PASS_PIXELS, RT_OPT_USE_BVH, RT_OPT_FILTER_FORM, RT_OPT_SHARED_CONSTANTS = 1, 2, 3, 4, 5, 6
+RT_OPT_EXACT_ONLY, RT_OPT_PROFILE, RT_OPT_PASS_PIXELS, RT_OPT_USE_BVH, RT_OPT_FILTER_FORM, RT_OPT_SHARED_CONSTANTS, RT_OPT_OVERLAP = 1, 2, 3, 4, 5, 6, 7
 
 
 class RtMaterial(C.Structure):

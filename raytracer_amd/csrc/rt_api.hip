@@ -118,16 +118,21 @@ struct rt_ctx {
     int occl_words = 1;
     DevBuf<double> rayq[2];        // [6][cap] each
     DevBuf<unsigned long long> keys[2];
-    DevBuf<double> aux;            // [6][cap]
-    DevBuf<uint32_t> occluded;     // [cap][occl_words]
+    DevBuf<double> aux[2];         // [6][cap], by level parity
+    DevBuf<uint32_t> occluded[2];  // [cap][occl_words], by level parity
     DevBuf<int32_t> pixel_of_ray;
     DevBuf<int32_t> lvl_parent, lvl_obj;   // [levels][cap]
     DevBuf<double> lvl_phong, lvl_child;   // [levels][3][cap]
     DevBuf<uint32_t> counts;       // [levels + 1]
-    DevBuf<uint8_t> ray_flags;     // [cap * max(1, n_lights)]
-    DevBuf<unsigned long long> pairs;
-    DevBuf<unsigned long long> pair_count;
-    size_t pair_cap = 0;
+    DevBuf<uint8_t> ray_flags[2];     // [cap * max(1, n_lights)]
+    // scratch of the trace launches, one set per kind of query ([0] nearest hit, [1] shadow) so
+    // that a level's shadow launches can run beside the next level's nearest-hit launches
+    DevBuf<unsigned long long> pairs[2];
+    DevBuf<unsigned long long> pair_count[2];
+    size_t pair_cap[2] = {0, 0};
+    hipStream_t side_stream = nullptr;    // the shadow/Phong half of a level runs here
+    std::vector<hipEvent_t> ev_hit, ev_phong;   // per level: k_hit done / k_phong done
+    int overlap = 1;                      // RT_OPT_OVERLAP
 
     // host copies kept so that the filter form can be switched after the upload
     std::vector<HostTri> h_tris;          // in Scene::objects order (triangles only)
@@ -203,8 +208,10 @@ int ensure_workspace(rt_ctx* c) {
         HIP_TRY(c->rayq[i].alloc(6 * want));
         HIP_TRY(c->keys[i].alloc(want));
     }
-    HIP_TRY(c->aux.alloc(6 * want));
-    HIP_TRY(c->occluded.alloc(want * c->occl_words));
+    for (int i = 0; i < 2; i++) {
+        HIP_TRY(c->aux[i].alloc(6 * want));
+        HIP_TRY(c->occluded[i].alloc(want * c->occl_words));
+    }
     HIP_TRY(c->pixel_of_ray.alloc(want));
     HIP_TRY(c->lvl_parent.alloc((size_t)levels * want));
     HIP_TRY(c->lvl_obj.alloc((size_t)levels * want));
@@ -213,11 +220,22 @@ int ensure_workspace(rt_ctx* c) {
     HIP_TRY(c->counts.alloc(levels + 2));
     const size_t shadow_rays = want * (size_t)std::max(1, c->hs.n_lights);
     if (shadow_rays >= (1ull << 31)) return fail(RT_ERR_RANGE, "pass too large: lower RT_OPT_PASS_PIXELS");
-    HIP_TRY(c->ray_flags.alloc(shadow_rays));
     // room for 16 listed pairs per ray of the largest launch (a few are typical), 8 B each
-    c->pair_cap = std::min<size_t>(std::max<size_t>(shadow_rays * 16, 1u << 20), 1u << 28);
-    HIP_TRY(c->pairs.alloc(c->pair_cap));
-    HIP_TRY(c->pair_count.alloc(2));      // [0] pairs listed, [1] k_filter's task counter
+    const size_t max_rays[2] = {want, shadow_rays};
+    for (int m = 0; m < 2; m++) {
+        HIP_TRY(c->ray_flags[m].alloc(max_rays[m]));
+        c->pair_cap[m] = std::min<size_t>(std::max<size_t>(max_rays[m] * 16, 1u << 20), 1u << 28);
+        HIP_TRY(c->pairs[m].alloc(c->pair_cap[m]));
+        HIP_TRY(c->pair_count[m].alloc(2));   // [0] pairs listed, [1] the task counter
+    }
+    if (!c->side_stream) HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    while ((int)c->ev_hit.size() < levels) {
+        hipEvent_t a = nullptr, b = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        c->ev_hit.push_back(a);
+        HIP_TRY(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        c->ev_phong.push_back(b);
+    }
     return 0;
 }
 
@@ -269,18 +287,19 @@ int launch_trace(rt_ctx* c, TraceArgs A, hipStream_t st, bool camera_rays = fals
     A.shared_origin_a = (MODE == 0 && camera_rays && c->shared_consts) ? c->eye_a.p : nullptr;
     A.shared_dir_rinv = (MODE == 1 && c->shared_consts && c->dir_rinv.n > 0) ? c->dir_rinv.p : nullptr;
     A.light_dir_row = c->light_dir_row.p;
-    A.ray_flags = c->ray_flags.p; A.pairs = c->pairs.p; A.pair_count = c->pair_count.p;
-    A.task_counter = (unsigned int*)(c->pair_count.p + 1);
-    A.pair_cap = (unsigned int)c->pair_cap; A.counters = c->counters.p; A.scan_all = c->force_exact;
-    HIP_TRY(hipMemsetAsync(c->pair_count.p, 0, 2 * sizeof(unsigned long long), st));
-    HIP_TRY(hipMemsetAsync(c->ray_flags.p, 0, c->ray_flags.n, st));
+    A.ray_flags = c->ray_flags[MODE].p; A.pairs = c->pairs[MODE].p; A.pair_count = c->pair_count[MODE].p;
+    A.task_counter = (unsigned int*)(c->pair_count[MODE].p + 1);
+    A.pair_cap = (unsigned int)c->pair_cap[MODE]; A.counters = c->counters.p; A.scan_all = c->force_exact;
+    HIP_TRY(hipMemsetAsync(c->pair_count[MODE].p, 0, 2 * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(c->ray_flags[MODE].p, 0, c->ray_flags[MODE].n, st));
     if (!c->force_exact && c->hs.n_regular > 0) {
         Timed t(c, st, MODE);
         if (c->use_bvh) {
             BvhArgs ba;
             ba.bvh = c->bvh_groups.p; ba.nodes = c->bvh_nodes.p; ba.filt = (const float*)c->tri_filt.p;
             ba.exact = c->tri_exact.p; ba.groups = c->groups.p; ba.xforms = c->xforms.p;
-            ba.spill = c->bvh_spill.p; ba.counters = (BvhCounters*)&c->counters.p->bvh_node_tests;
+            ba.spill = c->bvh_spill.p + (size_t)MODE * ((size_t)c->aux_grid * RT_BVH_BLOCK * RT_BVH_SPILL);   // one strip set per kind of query
+            ba.counters = (BvhCounters*)&c->counters.p->bvh_node_tests;
             hipLaunchKernelGGL(k_bvh_trace<MODE>, dim3(c->aux_grid), dim3(RT_BVH_BLOCK), 0, st, dsc, ba, A);
         } else {
             if (c->robust)
@@ -363,7 +382,7 @@ int build_bvh(rt_ctx* c) {
     }
     release_all();
     HIP_TRY(c->bvh_groups.upload(hb));
-    HIP_TRY(c->bvh_spill.alloc((size_t)c->aux_grid * RT_BVH_BLOCK * RT_BVH_SPILL));
+    HIP_TRY(c->bvh_spill.alloc(2 * (size_t)c->aux_grid * RT_BVH_BLOCK * RT_BVH_SPILL));
     c->bvh_built = true;
     return 0;
 }
@@ -379,39 +398,57 @@ int run_pass(rt_ctx* c, PassDesc pd, int nrows, hipStream_t st) {
     hipLaunchKernelGGL(k_primary, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, dsc, pd, n_pix, q[0], c->keys[0].p,
                        c->pixel_of_ray.p, c->frame, c->counts.p);
     HIP_TRY(hipGetLastError());
-    HitAux aux;
-    aux.nx = c->aux.p; aux.ny = c->aux.p + c->cap; aux.nz = c->aux.p + 2 * c->cap;
-    aux.vx = c->aux.p + 3 * c->cap; aux.vy = c->aux.p + 4 * c->cap; aux.vz = c->aux.p + 5 * c->cap;
+    // Per level: nearest hit -> k_hit on the caller's stream; shadow rays -> k_phong on the side
+    // stream, beside the next level's nearest-hit launches (both only read what k_hit wrote).
+    // The short launches of the deep levels then fill each other's idle SIMDs.  With event
+    // timing on (RT_OPT_PROFILE) everything stays on one stream so that a kernel's duration is
+    // its own.  Hit auxiliaries and occlusion bits alternate between two buffers by level
+    // parity; k_hit of level k+2 waits for k_phong of level k before it overwrites them.
+    const bool overlap = c->overlap && !c->profile && levels > 1;
+    hipStream_t sb = overlap ? c->side_stream : st;
     for (int k = 0; k < levels; k++) {
         const int cur = k & 1, nxt = cur ^ 1;
         LevelStore lvl = level_of(c, k);
+        double* ab = c->aux[cur].p;
+        HitAux aux;
+        aux.nx = ab; aux.ny = ab + c->cap; aux.nz = ab + 2 * c->cap;
+        aux.vx = ab + 3 * c->cap; aux.vy = ab + 4 * c->cap; aux.vz = ab + 5 * c->cap;
+        uint32_t* occl = c->occluded[cur].p;
         TraceArgs ta{};
         ta.rays = q[cur]; ta.n_items = c->counts.p + k; ta.keys = c->keys[cur].p;
         ta.occl_words = c->occl_words;
         int rc = launch_trace<0>(c, ta, st, k == 0);
         if (rc) return rc;
 
+        if (overlap && k >= 2) HIP_TRY(hipStreamWaitEvent(st, c->ev_phong[k - 2], 0));
         HitArgs ha{};
         ha.sc = dsc; ha.cur = q[cur]; ha.next = q[nxt]; ha.keys = c->keys[cur].p; ha.next_keys = c->keys[nxt].p;
         ha.n_rays = c->counts.p + k; ha.n_hits = c->counts.p + k + 1; ha.lvl = lvl; ha.aux = aux;
-        ha.occluded = c->occluded.p; ha.occl_words = c->occl_words;
+        ha.occluded = occl; ha.occl_words = c->occl_words;
         hipLaunchKernelGGL(k_hit, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, ha);
         HIP_TRY(hipGetLastError());
+        if (overlap) {
+            HIP_TRY(hipEventRecord(c->ev_hit[k], st));
+            HIP_TRY(hipStreamWaitEvent(sb, c->ev_hit[k], 0));
+        }
 
         if (c->hs.n_lights > 0) {
             TraceArgs sa{};
             sa.rays = q[nxt]; sa.n_items = c->counts.p + k + 1; sa.source_obj = lvl.obj;
-            sa.occluded = c->occluded.p; sa.occl_words = c->occl_words;
-            rc = launch_trace<1>(c, sa, st);
+            sa.occluded = occl; sa.occl_words = c->occl_words;
+            rc = launch_trace<1>(c, sa, sb);
             if (rc) return rc;
         }
 
         PhongArgs pa{};
-        pa.sc = dsc; pa.next = q[nxt]; pa.aux = aux; pa.lvl = lvl; pa.occluded = c->occluded.p;
+        pa.sc = dsc; pa.next = q[nxt]; pa.aux = aux; pa.lvl = lvl; pa.occluded = occl;
         pa.occl_words = c->occl_words; pa.cap = (uint32_t)c->cap; pa.n_hits = c->counts.p + k + 1;
-        hipLaunchKernelGGL(k_phong, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, pa);
+        hipLaunchKernelGGL(k_phong, dim3(c->aux_grid), dim3(RT_BLOCK), 0, sb, pa);
         HIP_TRY(hipGetLastError());
+        if (overlap) HIP_TRY(hipEventRecord(c->ev_phong[k], sb));
     }
+    // the fold (and whatever the caller enqueues next) comes after everything on the side stream
+    if (overlap) HIP_TRY(hipStreamWaitEvent(st, c->ev_phong[levels - 1], 0));
     for (int k = levels - 1; k >= 0; k--) {
         FoldArgs fa{};
         fa.sc = dsc; fa.lvl = level_of(c, k); fa.parent_lvl = level_of(c, k > 0 ? k - 1 : 0);
@@ -936,6 +973,7 @@ int rt_set_option(rt_ctx* c, int option, int64_t value) {
             return 0;
         }
         case RT_OPT_SHARED_CONSTANTS: c->shared_consts = value ? 1 : 0; return 0;
+        case RT_OPT_OVERLAP: c->overlap = value ? 1 : 0; return 0;
         case RT_OPT_USE_BVH:
             if (value) {
                 int rc = build_bvh(c);
@@ -1034,9 +1072,13 @@ void rt_free(rt_ctx* c) {
     c->obj_normals.release(); c->materials.release(); c->lights.release(); c->own_frame.release();
     c->counters.release();
     for (int i = 0; i < 2; i++) { c->rayq[i].release(); c->keys[i].release(); }
-    c->aux.release(); c->occluded.release(); c->pixel_of_ray.release(); c->lvl_parent.release();
+    for (int i = 0; i < 2; i++) { c->aux[i].release(); c->occluded[i].release(); }
+    c->pixel_of_ray.release(); c->lvl_parent.release();
     c->lvl_obj.release(); c->lvl_phong.release(); c->lvl_child.release(); c->counts.release();
-    c->ray_flags.release(); c->pairs.release(); c->pair_count.release();
+    for (int i = 0; i < 2; i++) { c->ray_flags[i].release(); c->pairs[i].release(); c->pair_count[i].release(); }
+    for (auto e : c->ev_hit) (void)hipEventDestroy(e);
+    for (auto e : c->ev_phong) (void)hipEventDestroy(e);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     c->bvh_nodes.release(); c->bvh_groups.release(); c->bvh_spill.release();
     c->eye_a.release(); c->dir_rinv.release(); c->light_dir_row.release();
     delete c;

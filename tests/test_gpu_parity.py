@@ -109,6 +109,30 @@ def test_shared_origin_and_direction_constants_change_nothing(name, w, h, depth)
             assert sa[k] == sb[k], (k, form)
 
 
+@pytest.mark.parametrize("name,w,h,depth,bvh", [("teapot", 320, 180, 5, False), ("mixed_xf", 320, 240, 6, False),
+                                               ("teapot", 320, 180, 5, True), ("input-06", 256, 192, 6, False)])
+def test_two_streams_give_the_frame_of_one(name, w, h, depth, bvh):
+    """A level's shadow launches run on an internal stream beside the next level's nearest-hit
+    launches; with RT_OPT_OVERLAP off everything runs on the caller's stream.  Same frame and
+    counts either way, also over several passes and repeated frames."""
+    from raytracer_amd.render import Renderer
+    sc = Scene.load(scene_file(name), w, h, depth)
+    frames = []
+    for overlap in (1, 0):
+        r = Renderer(sc)
+        r.set_option(abi.RT_OPT_OVERLAP, overlap)
+        r.set_option(abi.RT_OPT_PASS_PIXELS, w * 40)        # several passes per frame
+        if bvh:
+            r.set_option(abi.RT_OPT_USE_BVH, 1)
+        for _ in range(3):
+            r.render_frame()
+        frames.append((r.download(), r.stats()))
+        r.close()
+    assert np.array_equal(frames[0][0], frames[1][0])
+    for k in ("rays_primary", "rays_reflect", "rays_shadow", "hits"):
+        assert frames[0][1][k] == frames[1][1][k], k
+
+
 def test_filter_form_follows_the_scene():
     """Large smooth triangles take the cheap static margins; a mesh of triangles that are tiny
     against its scene, or that has walls of coplanar triangles, takes per-test margins and then
