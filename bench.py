@@ -102,7 +102,8 @@ def measured_traffic(kernel_label, launches_per_frame):
                 write = float(r["sum_over_dispatches"])
     if fetch is None or write is None or launches_per_frame <= 0:
         return None
-    return (2.0 * fetch + write) * 1024.0 / launches_per_frame   # the PMC pass profiles one frame
+    # the PMC passes run `bench.py --steps 1 --warmup 0 --no-lbvh`: two frames (timed + kernel-timing leg)
+    return (2.0 * fetch + write) * 1024.0 / (2.0 * launches_per_frame)
 
 
 def main():
