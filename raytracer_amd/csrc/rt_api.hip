@@ -164,7 +164,7 @@ struct rt_ctx {
     // options
     int force_exact = 0;
     int profile = 0;
-    long long pass_pixels = 4 << 20;
+    long long pass_pixels = 16 << 20;     // a 4K frame goes through in one pass (about 0.6 KB of workspace per pixel)
 
     int filter_grid[2] = {0, 0};
     int aux_grid = 0;
@@ -197,7 +197,10 @@ LevelStore level_of(rt_ctx* c, int k) {
 
 int ensure_workspace(rt_ctx* c) {
     size_t frame_px = (size_t)c->hs.width * c->hs.height;
-    size_t want = (size_t)std::min<long long>((long long)frame_px, std::max<long long>(c->pass_pixels, c->hs.width));
+    // shadow rays of a pass are numbered with 31 bits
+    const long long by_lights = ((1ll << 31) - 1) / std::max(1, c->hs.n_lights);
+    const long long budget = std::max<long long>(std::min<long long>(c->pass_pixels, by_lights), c->hs.width);
+    size_t want = (size_t)std::min<long long>((long long)frame_px, budget);
     // whole rows per pass
     want = std::max<size_t>(c->hs.width, want / c->hs.width * c->hs.width);
     int levels = c->hs.max_depth + 1;
