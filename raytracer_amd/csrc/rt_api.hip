@@ -85,7 +85,7 @@ template <class T> struct DevBuf {
 }  // namespace
 
 // One triangle as the host keeps it: the reference-precision record and the filter record in
-// both forms (static worst-case margins / per-test margins), see filter_keep2.
+// both forms (static worst-case margins / per-test margins), see filter_z2.
 struct HostTri {
     TriExact ex;
     float f_static[16], f_robust[16];
@@ -144,7 +144,7 @@ struct rt_ctx {
     int auto_robust = 0;                  // the form chosen from the scene's own numbers
     int robust = 0;                       // the form installed now
 
-    // per-triangle constants shared by all rays of a launch (see filter_keep2)
+    // per-triangle constants shared by all rays of a launch (see filter_z2)
     DevBuf<float> eye_a;                  // [n_regular + 1]
     DevBuf<float> dir_rinv;               // [directional lights][n_regular + 1]
     DevBuf<int32_t> light_dir_row;        // [n_lights]

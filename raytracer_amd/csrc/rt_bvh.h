@@ -154,7 +154,7 @@ __global__ void k_bvh_refit(const TriExact* __restrict__ exact, const int* __res
 struct BvhCounters { unsigned long long node_tests, leaf_tests; };
 
 // The brute-force filter's test for ONE ray and a triangle record fetched per lane (same
-// arithmetic as filter_keep2; `robust` selects the per-test margin f[13 + mode]).
+// arithmetic as filter_z2; `robust` selects the per-test margin f[13 + mode]).
 // *r_lo_out: a lower bound of the ray parameter the reference would compute for the pair.
 __device__ __forceinline__ bool filter_keep1(const float* __restrict__ f, int axis, float px, float py, float pz,
                                              float vx, float vy, float vz, const GroupFilter& Q, const bool robust,

@@ -16,7 +16,7 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(4))) const v16f cv16f;
 
-// Regular triangle, FP32 filter form: 16 floats (layout at filter_keep in rt_kernels.h).
+// Regular triangle, FP32 filter form: 16 floats (layout at filter_z2 in rt_kernels.h).
 // Reference-precision form of the same triangle (128 bytes):
 struct __attribute__((aligned(16))) TriExact {
     double v1[3];      // vertex1
@@ -85,7 +85,7 @@ struct DevScene {
     int32_t n_objects, n_lights, n_transforms, last_xf;
     int32_t width, height, max_depth, pad0;
     float eps, shadow_eps;
-    int32_t robust_filter;       // 1: filter records carry per-test margins (see filter_keep2)
+    int32_t robust_filter;       // 1: filter records carry per-test margins (see filter_z2)
     int32_t pad1;
     double cam_eye[3], cam_ll[3], cam_lr[3], cam_ul[3], cam_ur[3];
     double ambient[3];

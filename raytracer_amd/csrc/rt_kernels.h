@@ -1,22 +1,23 @@
 // The trace loop as a wavefront pipeline.  One "level" is one generation of
 // rays (level 0 = camera rays, level k = k-th reflection).  Per level:
-//   k_closest  nearest hit of every ray in the level's queue (brute force)
-//   k_hit      compacts the rays that hit something (ballot + one atomic per
-//              wave), computes hit point, normal and reflection, and writes
-//              the next level's ray queue
-//   k_anyhit   one shadow ray per (hit, light)
-//   k_phong    Phong sum over the unshadowed lights
+//   nearest hit  of every ray in the level's queue  (k_filter<0> -> k_exact_pairs<0>, k_brute<0>)
+//   k_hit        compacts the rays that hit something (ballot + one atomic per
+//                wave), computes hit point, normal and reflection, and writes
+//                the next level's ray queue
+//   shadow rays  one per (hit, light)               (k_filter<1> -> k_exact_pairs<1>, k_brute<1>)
+//   k_phong      Phong sum over the unshadowed lights
 // and after the last level k_fold walks the levels deepest-first to evaluate
 //   phong_0 + kr_0 * (phong_1 + kr_1 * (...))            (raytracer.cpp:542-543)
 // in the reference's order.  Queue lengths live in device memory; nothing
 // is read back by the host between kernels.
 //
-// k_closest / k_anyhit scan every primitive for every ray.  Regular triangles
+// The trace kernels scan every primitive for every ray.  Regular triangles
 // go through an FP32 filter (16 floats per triangle, wave-uniform, so the
 // compiler fetches them with scalar loads and they never occupy vector
-// registers); pairs the filter cannot rule out are queued per lane in LDS and
-// re-evaluated in the reference's mixed double/float arithmetic, so every
-// accept/reject decision and every hit distance is the reference's own.
+// registers); pairs the filter cannot rule out are staged per lane in LDS, listed
+// in global memory and re-evaluated in the reference's mixed double/float
+// arithmetic, so every accept/reject decision and every hit distance is the
+// reference's own.
 #pragma once
 
 #include "rt_device.h"
@@ -183,21 +184,31 @@ __device__ __forceinline__ void publish_result(const TraceArgs& A, unsigned int 
     }
 }
 
-// The FP32 filter for one (ray, triangle) pair: false only when the reference-precision
+// The FP32 filter for one (ray, triangle) pair: it may reject only when the reference-precision
 // test of the pair is certain to miss.  Record f (wave-uniform, in scalar registers):
 //   f[0..3]   unit normal n and d0 = n.v1
 //   f[4..6]   s as an affine function of the hit point's two coordinates OTHER than the
 //             normal's dominant axis (the third follows from the plane equation),
-//   f[7..9]   t likewise, f[10..12] u = 1 - s - t likewise; every offset includes the margin.
+//   f[7..9]   t likewise, f[10..12] u = 1 - s - t likewise; every offset includes the margin,
+//   f[13,14]  per-test margin coefficients (ROBUST form), f[15] the largest static margin.
 // (pu, pv, vu, vv): those two coordinates of the ray origin and direction.
 // Q: the query's thresholds for the triangle's group (GroupFilter).
-// Every comparison is false for NaN, so NaN never rejects.  A ray too parallel to the plane
-// needs no test of its own: the reference then misses unless the origin lies on the plane
-// (raytracer.cpp:319-325), which the last term keeps.
+//
+// With b = n.dir, a = d0 - n.origin, r = a / b and (s, t, u) evaluated at origin + r dir, the
+// pair is kept when z = min(s, t, u, r - r_lo) >= 0, or when the origin may lie exactly in the
+// plane (|a| <= a_zero; raytracer.cpp:319-325 -- a ray too parallel to the plane needs no test
+// of its own: the reference then misses unless that is the case).  Per ray this function
+// produces the ONE number z, so that the scan loop can ask "does any of my 8 rays keep this
+// triangle?" with a maximum over the z's and a single comparison, instead of three comparisons
+// per ray whose results have to be merged on the scalar unit.  min/max drop a NaN operand, so
+// a NaN among s, t, u can only make the test keep more; z itself is NaN only for 0 * inf
+// (origin in the plane AND direction in it), a pair the in-plane term keeps -- *a_min collects
+// the smallest |a| of the lane's rays for it.
+//
 // Two rays at a time: MI355X reaches its FP32 vector peak only through the packed
 // instructions (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth of FMAs per issue slot), so the
 // lane's rays are kept as float2 pairs and every multiply-add of the test is a packed one.
-// Reciprocal, min3 and the comparisons have no packed form and stay per ray.
+// Reciprocal and min/max have no packed form and stay per ray.
 //
 // ROBUST = false: the margins in the offsets are the worst case over every ray the group can
 // meet (the most grazing one included) -- the cheapest test, right for scenes whose triangles
@@ -205,7 +216,7 @@ __device__ __forceinline__ void publish_result(const TraceArgs& A, unsigned int 
 // ROBUST = true: the offsets carry only the ray-independent part; the part that grows with
 // 1/|n.dir| is added per test from f[13 + MODE] (nearest hit / shadow), and the in-plane-origin
 // term also requires a grazing ray, so a ray leaving a flat wall does not list every triangle
-// of that wall.  Two more instructions per ray; chosen per scene when it is uploaded.
+// of that wall.  One more instruction per ray; chosen per scene when it is uploaded.
 //
 // SHARED: what all rays of the task have in common, with the matching per-triangle constant
 // `shared` computed on the host in double precision (at least as accurate as the FP32
@@ -215,65 +226,6 @@ __device__ __forceinline__ void publish_result(const TraceArgs& A, unsigned int 
 //      three multiply-adds and the reciprocal go.
 struct FilterQuery { float r_lo, a_zero, b_hi; };
 
-template <int MODE, bool ROBUST, int SHARED>
-__device__ __forceinline__ void filter_keep2(const v16f f, v2f px, v2f py, v2f pz, v2f vx, v2f vy, v2f vz,
-                                             v2f pu, v2f pv, v2f vu, v2f vv, const FilterQuery Q, const float shared,
-                                             bool* keep0, bool* keep1) {
-    const v2f n0 = {f[0], f[0]}, n1 = {f[1], f[1]}, n2 = {f[2], f[2]}, d0 = {f[3], f[3]};
-    v2f a, b, rinv;
-    if (SHARED == 2) {
-        rinv.x = rinv.y = shared;
-        b.x = b.y = 0.0f;               // not used: the grazing test below reads 1/b
-    } else {
-        b = n0 * vx;
-        b = __builtin_elementwise_fma(n1, vy, b);
-        b = __builtin_elementwise_fma(n2, vz, b);
-        rinv.x = __builtin_amdgcn_rcpf(b.x); rinv.y = __builtin_amdgcn_rcpf(b.y);
-    }
-    if (SHARED == 1) {
-        a.x = a.y = shared;
-    } else {
-        a = __builtin_elementwise_fma(-n0, px, d0);
-        a = __builtin_elementwise_fma(-n1, py, a);
-        a = __builtin_elementwise_fma(-n2, pz, a);
-    }
-    const v2f r = a * rinv;
-    const v2f hu = __builtin_elementwise_fma(r, vu, pu);
-    const v2f hv = __builtin_elementwise_fma(r, vv, pv);
-    const v2f c4 = {f[4], f[4]}, c5 = {f[5], f[5]}, c6 = {f[6], f[6]};
-    const v2f c7 = {f[7], f[7]}, c8 = {f[8], f[8]}, c9 = {f[9], f[9]};
-    const v2f c10 = {f[10], f[10]}, c11 = {f[11], f[11]}, c12 = {f[12], f[12]};
-    const v2f s = __builtin_elementwise_fma(c4, hu, __builtin_elementwise_fma(c5, hv, c6));
-    const v2f t = __builtin_elementwise_fma(c7, hu, __builtin_elementwise_fma(c8, hv, c9));
-    const v2f u = __builtin_elementwise_fma(c10, hu, __builtin_elementwise_fma(c11, hv, c12));
-    float m0 = __builtin_fminf(__builtin_fminf(s.x, t.x), u.x);
-    float m1 = __builtin_fminf(__builtin_fminf(s.y, t.y), u.y);
-    if (ROBUST) {
-        const float gm = f[13 + MODE];
-        m0 = __builtin_fmaf(gm, fabsf(rinv.x), m0);
-        m1 = __builtin_fmaf(gm, fabsf(rinv.y), m1);
-    }
-    const bool reject0 = (m0 < 0.0f) | (r.x < Q.r_lo);
-    const bool reject1 = (m1 < 0.0f) | (r.y < Q.r_lo);
-    if (ROBUST && SHARED == 2) {
-        const bool grazing = !(fabsf(shared) * Q.b_hi < 1.0f);      // |b| <= b_hi, or NaN
-        *keep0 = (!reject0) | ((fabsf(a.x) <= Q.a_zero) & grazing);
-        *keep1 = (!reject1) | ((fabsf(a.y) <= Q.a_zero) & grazing);
-    } else if (ROBUST) {
-        *keep0 = (!reject0) | ((fabsf(a.x) <= Q.a_zero) & (fabsf(b.x) <= Q.b_hi));
-        *keep1 = (!reject1) | ((fabsf(a.y) <= Q.a_zero) & (fabsf(b.y) <= Q.b_hi));
-    } else {
-        *keep0 = (!reject0) | (fabsf(a.x) <= Q.a_zero);
-        *keep1 = (!reject1) | (fabsf(a.y) <= Q.a_zero);
-    }
-}
-
-// The same test in the form the scan loop uses: per ray ONE number z = min(s, t, u, r - r_lo)
-// (z >= 0: not rejected), so that the wave can ask "does any of my 8 rays keep this triangle?"
-// with a maximum over the z's and a single comparison, instead of three comparisons per ray
-// whose results have to be merged on the scalar unit.  A NaN z (0 * inf: origin on the plane AND
-// direction in it) drops out of that maximum; such a pair is kept by the in-plane-origin
-// term, for which *a_min collects the smallest |a| of the lane's rays.
 template <int MODE, bool ROBUST, int SHARED>
 __device__ __forceinline__ void filter_z2(const v16f f, v2f px, v2f py, v2f pz, v2f vx, v2f vy, v2f vz,
                                           v2f pu, v2f pv, v2f vu, v2f vv, const FilterQuery Q, const float shared,
@@ -521,7 +473,7 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
         const int part = __builtin_amdgcn_readfirstlane((int)(task / n_ray_blocks));
         const unsigned int rb = task - (unsigned int)part * n_ray_blocks;
         const unsigned int ray0 = rb * RAYS_PER_TASK + lane;          // slot r: ray0 + r * 64
-        // What the task's rays share (see filter_keep2): camera rays their origin; shadow rays
+        // What the task's rays share (see filter_z2): camera rays their origin; shadow rays
         // towards one directional light their direction.
         int shared_kind = 0;
         const cfloat* shared = nullptr;
@@ -761,7 +713,7 @@ k_brute(const DevScene* __restrict__ sc, const TriExact* __restrict__ exact, Tra
 }
 
 // ---------------------------------------------------------------------------
-// After k_closest: the part of Scene::traceRay behind the object loop
+// After the nearest-hit kernels: the part of Scene::traceRay behind the object loop
 // (raytracer.cpp:531-538) for every ray that hit, compacted.
 // ---------------------------------------------------------------------------
 struct HitArgs {
