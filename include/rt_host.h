@@ -6,7 +6,7 @@
  * and produces the flat rt_scene_desc that rt_upload_scene takes, plus the
  * PNG writer standing where Film::writeFile calls lodepng::encode
  * (raytracer.cpp:205-235).  The reference itself would not use this loader:
- * it would flatten its own Scene object (INTEGRATION.md shows that binding).
+ * it would flatten its own Scene object (oracle/ref_wrapper.cpp does exactly that walk).
  */
 #ifndef RT_HOST_H
 #define RT_HOST_H

@@ -16,8 +16,8 @@
 //  * writes the RGBA8 image exactly as Film::writeFile (raytracer.cpp:205-230)
 //    would hand it to lodepng: row 0 is the TOP scanline = film row H-1,
 //  * optionally dumps the parsed scene as the flat "RTSD" description that
-//    rt_upload_scene takes (this is the reference-side binding shown in
-//    INTEGRATION.md; the format is documented in include/rt_abi.h),
+//    rt_upload_scene takes (this walk over the reference's public members is
+//    the reference-side binding; the format is documented in include/rt_abi.h),
 //  * prints one JSON line with the wall time of the trace loop only.
 //
 // The working directory is changed to the scene's directory first because the
