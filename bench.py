@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exact-only", action="store_true")
     ap.add_argument("--no-lbvh", action="store_true", help="skip the extra LBVH-mode measurement")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1 (nccl = RCCL; gloo stages through host memory and exists to "
+                         "rehearse the N-rank flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="one stream: no overlap of a level's shadow launches with the next level's nearest-hit launches")
     return ap.parse_args()
@@ -117,8 +120,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
+        local_rank %= max(1, torch.cuda.device_count())      # (more ranks than devices: a rehearsal on a smaller box)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -130,7 +137,9 @@ def main():
     frame = torch.zeros((args.height, args.width, 4), dtype=torch.uint8, device=dev)
     r.bind_frame(frame)
     stream = torch.cuda.current_stream().cuda_stream
-    exchange = TileGather(args.height, args.width, args.tile_rows, rank, world, dev, dist=dist, torch=torch)
+    exchange = TileGather(args.height, args.width, args.tile_rows, rank, world, dev, dist=dist, torch=torch,
+                          host_staging=args.backend != "nccl")
+    coll_dev = dev if args.backend == "nccl" else torch.device("cpu")      # where the small reductions live
 
     def step():
         r.render_tiles(rank, args.tile_rows, world, stream)
@@ -189,7 +198,7 @@ def main():
         r.set_option(abi.RT_OPT_USE_BVH, 0)
         lb_rays = sb["rays_primary"] + sb["rays_reflect"] + sb["rays_shadow"]
         if world > 1:
-            tt = torch.tensor([lb_elapsed, float(lb_rays)], dtype=torch.float64, device=dev)
+            tt = torch.tensor([lb_elapsed, float(lb_rays)], dtype=torch.float64, device=coll_dev)
             mx = tt.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
             sm = tt.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
             lb_elapsed, lb_rays_total = float(mx[0].item()), float(sm[1].item())
@@ -203,11 +212,11 @@ def main():
 
     rays_local = st_timed["rays_primary"] + st_timed["rays_reflect"] + st_timed["rays_shadow"]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         cnt = torch.tensor([rays_local, st_timed["rays_primary"], st_timed["rays_reflect"], st_timed["rays_shadow"]],
-                           dtype=torch.int64, device=dev)
+                           dtype=torch.int64, device=coll_dev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         rays_total, n_primary, n_reflect, n_shadow = [int(v) for v in cnt.tolist()]
     else:
@@ -252,12 +261,13 @@ def main():
                          "peak_from_device_properties": {"compute_units": n_cu,
                                                          "clock_mhz": clock_khz / 1e3 if clock_khz else None,
                                                          "tflops": device_peak / 1e12 if device_peak else None},
-                         "traffic": measured_traffic(dom, launches / max(1, args.steps)),
+                         # (the committed PMC pass is a 1-GPU run: its per-launch bytes describe N = 1 only)
+                         "traffic": measured_traffic(dom, launches / max(1, args.steps)) if world == 1 else None,
                          "kernel_ms_avg": ms / max(1, launches), "launches": launches,
                          "timing": "HIP events on the launch stream, K frames after the timed region with the "
                                    "library's two streams serialised (%.2f ms per frame that way)" % (serial_elapsed / args.steps * 1e3),
-                         "whole_frame_tflops_in_timed_region": (st["closest_tests"] + st["anyhit_tests"]) * flop_per_test
-                                                               / args.steps / (elapsed / args.steps) / 1e12,
+                         "rank0_whole_frame_tflops_in_timed_region": (st["closest_tests"] + st["anyhit_tests"]) * flop_per_test
+                                                                     / args.steps / (elapsed / args.steps) / 1e12,
                          "flop_per_test": flop_per_test, "tests_per_launch": tests / max(1, launches),
                          "both_filter_kernels_tflops": both / 1e12,
                          "filter_ms_per_step": both_ms / args.steps,

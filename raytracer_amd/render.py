@@ -114,18 +114,22 @@ class TileGather:
     """End-of-frame exchange, set up once per (frame size, tiling, rank): every rank sends the
     rows of its tiles to rank 0, which writes them into its frame.  The collective is
     torch.distributed.gather (RCCL over xGMI on GPUs, gloo on CPU).  Index tensors and
-    staging buffers are built here, not per frame."""
+    staging buffers are built here, not per frame.  `host_staging` sends the packed rows
+    through host memory (for a backend that has no device-memory gather, i.e. gloo with the
+    frame on a GPU)."""
 
-    def __init__(self, height, width, tile_rows, rank, world, device, dist=None, torch=None):
+    def __init__(self, height, width, tile_rows, rank, world, device, dist=None, torch=None, host_staging=False):
         self.rank, self.world, self.dist, self.torch = rank, world, dist, torch
+        self.host_staging = host_staging
         rows, padded = pack_rows(None, height, tile_rows, rank, world)
         self.n_rows = len(rows)
         self.idx = torch.as_tensor(rows, dtype=torch.long, device=device)
         self.send = torch.zeros((padded, width, 4), dtype=torch.uint8, device=device)
         self.recv = None
         self.peer_idx = {}
+        coll_device = "cpu" if host_staging else device
         if rank == 0 and world > 1:
-            self.recv = [torch.empty_like(self.send) for _ in range(world)]
+            self.recv = [torch.empty((padded, width, 4), dtype=torch.uint8, device=coll_device) for _ in range(world)]
             for r in range(1, world):
                 rrows, _ = pack_rows(None, height, tile_rows, r, world)
                 self.peer_idx[r] = torch.as_tensor(rrows, dtype=torch.long, device=device)
@@ -136,11 +140,11 @@ class TileGather:
         torch = self.torch
         if self.n_rows:
             torch.index_select(frame, 0, self.idx, out=self.send[: self.n_rows])
-        self.dist.gather(self.send, self.recv, dst=0)
+        self.dist.gather(self.send.cpu() if self.host_staging else self.send, self.recv, dst=0)
         if self.rank == 0:
             for r, ridx in self.peer_idx.items():
                 if ridx.numel():
-                    frame.index_copy_(0, ridx, self.recv[r][: ridx.numel()])
+                    frame.index_copy_(0, ridx, self.recv[r][: ridx.numel()].to(frame.device))
         return frame
 
 
