@@ -122,3 +122,27 @@ def test_config5_million_triangles_8k_through_the_lbvh(oracle, tmp_path):
     assert np.array_equal(a, b)
     for key in ("rays_reflect", "rays_shadow", "hits"):
         assert sa[key] == sb[key], key
+
+
+def test_two_rank_benchmark_flow_on_one_gpu():
+    """The N-rank driver end to end with two ranks sharing this box's GPU (gloo instead of
+    RCCL, which refuses two ranks on one device): interleaved tiles per rank, gather to rank 0,
+    max-over-ranks timing, summed ray counts.  The ray total must be the single-process one."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    common = ["--steps", "1", "--warmup", "0", "--width", "640", "--height", "360", "--no-cpu-baseline", "--no-lbvh"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common,
+                         check=True, capture_output=True, text=True, timeout=300).stdout
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--backend", "gloo"] + common,
+                         check=True, capture_output=True, text=True, timeout=300).stdout
+    a = json.loads(one.strip().splitlines()[-1])
+    b = json.loads([ln for ln in two.strip().splitlines() if ln.startswith("{")][-1])
+    assert a["n_gpus"] == 1 and b["n_gpus"] == 2 and b["value"] > 0
+    assert a["config"]["rays_per_frame"] == b["config"]["rays_per_frame"]
