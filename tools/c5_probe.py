@@ -23,6 +23,11 @@ for bvh in modes:
     print(f'bvh={bvh}: upload {t4-t3:.2f}s build {t5-t4:.2f}s render {t6-t5:.2f}s rays {rays} -> {rays/(t6-t5)/1e6:.1f} Mrays/s '
           f'flagged {st["flagged_rays"]} exact {st["exact_tests"]} box/ray {st["bvh_node_tests"]/max(1,rays):.1f} leaf/ray {st["bvh_leaf_tests"]/max(1,rays):.2f} irregular {st["n_irregular"]} '
           f'closest_ms {st["closest_ms"]:.1f} anyhit_ms {st["anyhit_ms"]:.1f} exact_ms {st["exact_ms"]:.1f}', flush=True)
+    if not bvh:
+        tests = st['closest_tests'] + st['anyhit_tests']
+        ms = st['closest_ms'] + st['anyhit_ms']
+        tri_share = st['n_triangles'] / (st['n_triangles'] + st['n_spheres'])
+        print(f'    brute force: {tests * tri_share * 42 / (ms * 1e-3) / 1e12:.1f} TFLOP/s in the filter kernels (form {st["filter_form"]})', flush=True)
     res[bvh] = img
 if len(res) == 2:
     print('identical:', np.array_equal(res[0], res[1]), 'differing pixels:', int((res[0] != res[1]).any(axis=-1).sum()))
