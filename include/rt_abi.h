@@ -159,6 +159,14 @@ int rt_bind_frame(rt_ctx* ctx, void* device_rgba, size_t bytes);
  * rendered are black. */
 int rt_download(rt_ctx* ctx, uint8_t* rgba, size_t bytes);
 
+/* Known-answer hook for parity tests: the nearest hit of the camera ray of every pixel of film
+ * rows [y0, y0 + rows), row-major from row y0 (the object loop of Scene::traceRay,
+ * raytracer.cpp:516-529, and nothing after it).  keys[i] = (bit pattern of the float metric d
+ * << 32) | index of the object in Scene::objects order; a miss is 0x7f7fffffffffffff.  Honours
+ * the options (filter form, LBVH, exact-only).  Blocks; runs on the default stream; leaves those
+ * rows of the frame black. */
+int rt_primary_hits(rt_ctx* ctx, int y0, int rows, uint64_t* keys, size_t count);
+
 int rt_get_stats(rt_ctx* ctx, rt_stats* out);   /* waits for the ctx's work */
 int rt_reset_stats(rt_ctx* ctx);
 

@@ -1005,6 +1005,37 @@ int rt_render_tiles(rt_ctx* c, int first_tile, int tile_rows, int tile_step, voi
     return render_rows(c, first_tile * tile_rows, tile_rows, tile_step * tile_rows, n_mine, (hipStream_t)stream);
 }
 
+int rt_primary_hits(rt_ctx* c, int y0, int rows, uint64_t* keys, size_t count) {
+    if (!c || !keys) return fail(RT_ERR_ARG, "rt_primary_hits: null argument");
+    if (rows <= 0 || y0 < 0 || (long long)y0 + rows > c->hs.height)
+        return fail(RT_ERR_RANGE, "rt_primary_hits: rows outside the frame");
+    const int W = c->hs.width;
+    if (count < (size_t)rows * W) return fail(RT_ERR_RANGE, "rt_primary_hits: buffer too small");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_workspace(c);
+    if (rc) return rc;
+    const int rows_per_pass = (int)(c->cap / W);
+    hipStream_t st = nullptr;
+    const DevScene* dsc = c->d_scene.p;
+    for (int q0 = 0; q0 < rows; q0 += rows_per_pass) {
+        const int nrows = std::min(rows_per_pass, rows - q0);
+        const int n_pix = nrows * W;
+        PassDesc pd{y0, rows, rows, q0};
+        HIP_TRY(hipMemsetAsync(c->counts.p, 0, (c->levels + 2) * sizeof(uint32_t), st));
+        RayQueue q = queue_of(c->rayq[0], c->cap);
+        hipLaunchKernelGGL(k_primary, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, dsc, pd, n_pix, q, c->keys[0].p,
+                           c->pixel_of_ray.p, c->frame, c->counts.p);
+        HIP_TRY(hipGetLastError());
+        TraceArgs ta{};
+        ta.rays = q; ta.n_items = c->counts.p; ta.keys = c->keys[0].p; ta.occl_words = c->occl_words;
+        rc = launch_trace<0>(c, ta, st, true);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(keys + (size_t)q0 * W, c->keys[0].p, (size_t)n_pix * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
 int rt_bind_frame(rt_ctx* c, void* device_rgba, size_t bytes) {
     if (!c) return fail(RT_ERR_ARG, "rt_bind_frame: null ctx");
     if (!device_rgba) { c->frame = c->own_frame.p; return 0; }

@@ -65,6 +65,19 @@ class Renderer:
         _check(self._lib, self._lib.rt_download(self._ctx, out.ctypes.data_as(C.c_void_p), out.nbytes), "rt_download")
         return out
 
+    def primary_hits(self, y0=0, rows=None):
+        """Nearest hit of every camera ray of film rows [y0, y0 + rows): (object index or -1,
+        float metric d) per pixel, shape [rows, width], row 0 = film row y0."""
+        rows = self.height - y0 if rows is None else rows
+        keys = np.empty((rows, self.width), dtype=np.uint64)
+        _check(self._lib, self._lib.rt_primary_hits(self._ctx, int(y0), int(rows), keys.ctypes.data_as(C.c_void_p),
+                                                    keys.size), "rt_primary_hits")
+        miss = keys == np.uint64(0x7F7FFFFFFFFFFFFF)
+        obj = (keys & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        obj[miss] = -1
+        d = (keys >> np.uint64(32)).astype(np.uint32).view(np.float32)
+        return obj.astype(np.int32), d
+
     def stats(self):
         st = abi.RtStats()
         _check(self._lib, self._lib.rt_get_stats(self._ctx, C.byref(st)), "rt_get_stats")

@@ -160,8 +160,9 @@ def test_counts_match_oracle(name, w, h, depth, oracle):
     assert st["closest_tests"] == c["closest_tests"]
 
 
-AUTHORS = [("input-02", "image-02"), ("input-05", "image-05"), ("input-06", "image-06"), ("input-07", "image-07"),
-           ("input-08", "image-08"), ("input-11", "image-11")]
+# every scene / render pair the reference's authors left behind (1000 x 1000, depth 6)
+AUTHORS = [("input-%02d" % k, "image-%02d" % k) for k in range(1, 12)] + [
+    ("scene1", "scene1"), ("sphere", "sphere2"), ("s1", "output"), ("s2", "output-01")]
 
 
 @pytest.mark.parametrize("scene,image", AUTHORS, ids=[a[0] for a in AUTHORS])
