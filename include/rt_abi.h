@@ -92,7 +92,7 @@ typedef enum rt_option {
     RT_OPT_USE_BVH = 4,      /* 1: build (once) and use the LBVH in place of the brute-force triangle scan */
     RT_OPT_FILTER_FORM = 5,  /* form of the FP32 candidate filter: 0 = chosen from the scene when it was
                                 uploaded (default), 1 = static worst-case margins (cheapest test), 2 = per-test
-                                margins (two more instructions per test; for meshes of triangles that are
+                                margins (one more instruction per test; for meshes of triangles that are
                                 tiny against the scene, or with many triangles in one plane).  Frames are
                                 identical in every form; blocks until queued work has finished */
     RT_OPT_SHARED_CONSTANTS = 6, /* 1 (default): the brute-force filter reads host-computed per-triangle constants
