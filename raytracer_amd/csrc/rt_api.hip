@@ -2,6 +2,8 @@
 // per-primitive precomputation, the pass scheduler that strings the kernels of
 // rt_kernels.h together, download and statistics.
 #include "rt_abi.h"
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <unordered_map>
 #include <string.h>
@@ -71,11 +73,12 @@ template <class T> struct DevBuf {
         if (count == 0) return hipSuccess;
         return hipMalloc((void**)&p, count * sizeof(T));
     }
-    hipError_t upload(const std::vector<T>& v) {
-        hipError_t e = alloc(v.size());
-        if (e != hipSuccess || v.empty()) return e;
-        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    hipError_t upload(const T* src, size_t count) {
+        hipError_t e = alloc(src ? count : 0);
+        if (e != hipSuccess || !src || count == 0) return e;
+        return hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
     }
+    hipError_t upload(const std::vector<T>& v) { return upload(v.data(), v.size()); }
     void release() {
         if (p) (void)hipFree(p);
         p = nullptr; n = 0;
@@ -654,6 +657,15 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
     c->clock_khz = prop.clockRate;
 
     const int NX = d->n_transforms;
+    // RT_UPLOAD_TIMING in the environment: print how long each phase of the upload took (stderr)
+    const bool timing = std::getenv("RT_UPLOAD_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "rt_upload_scene: %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_prev).count());
+        t_prev = now;
+    };
     // ---- transforms ----
     std::vector<double> xf(48 * (size_t)NX);
     std::vector<int32_t> xf_ident(NX);
@@ -692,6 +704,7 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
         }
     }
 
+    lap("bounds");
     // ---- per transform and kind of query: the magnitudes the filter's operands can have ----
     // Nearest-hit rays reach a group in its object space (raytracer.cpp:251-259): origins are the
     // world box under M^-1, camera directions are unnormalised, later directions have unit
@@ -870,10 +883,15 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
     c->h_xf = xf;
     c->scene_bound = R_max;
 
+    lap("triangle records");
     // ---- which form of the filter: the cheap static margins unless they are useless here ----
     {
         double sum = 0; size_t n_ok = 0, n_only_robust = 0;
-        std::unordered_map<unsigned long long, int> planes;
+        // plane -> number of triangles in it: open addressing over twice as many slots as triangles
+        size_t n_slots = 16;
+        while (n_slots < 2 * tris.size()) n_slots *= 2;
+        std::vector<unsigned long long> slot_key(n_slots, 0);
+        std::vector<int> slot_count(n_slots, 0);
         int largest_plane = 0;
         for (const HostTri& t : tris) {
             if (t.ok_robust && !t.ok_static) n_only_robust++;
@@ -886,7 +904,11 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
                 const double scale = q < 3 ? 2048.0 : 2048.0 / std::max(mag0[t.xf].R, 1e-30);
                 key = (key ^ (unsigned long long)(long long)std::llround(f[q] * scale)) * 0x100000001B3ull;
             }
-            largest_plane = std::max(largest_plane, ++planes[key]);
+            key |= 1ull;                                    // 0 marks an empty slot
+            size_t at = (size_t)(key >> 17) & (n_slots - 1);
+            while (slot_key[at] != 0 && slot_key[at] != key) at = (at + 1) & (n_slots - 1);
+            slot_key[at] = key;
+            largest_plane = std::max(largest_plane, ++slot_count[at]);
         }
         const double mean_margin = n_ok ? sum / (double)n_ok : 0.0;
         c->auto_robust = (n_only_robust > 0 || mean_margin > 1.0 || largest_plane > 16) ? 1 : 0;
@@ -901,20 +923,17 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
     static_assert(sizeof(DevLight) == sizeof(rt_light), "light layout");
     static_assert(sizeof(TriExact) == 128, "TriExact layout");
 
-    std::vector<int32_t> kind(d->obj_kind, d->obj_kind + N), omat(d->obj_material, d->obj_material + N),
-        oxf(d->obj_transform, d->obj_transform + N), ointerp(d->obj_interp, d->obj_interp + N);
-    std::vector<double> geom(d->obj_geom, d->obj_geom + 9 * (size_t)N);
-    std::vector<double> nrm;
-    if (d->obj_normals) nrm.assign(d->obj_normals, d->obj_normals + 9 * (size_t)N);
-
-#define UP(buf, vec)                                                                                   \
+#define UP(buf, ...)                                                                                   \
     do {                                                                                               \
-        hipError_t e_ = c->buf.upload(vec);                                                            \
+        hipError_t e_ = c->buf.upload(__VA_ARGS__);                                                    \
         if (e_ != hipSuccess) return bail(fail(RT_ERR_DEVICE, std::string("upload " #buf ": ") + hipGetErrorString(e_))); \
     } while (0)
-    UP(spheres, sph); UP(xforms, xf);
-    UP(xf_identity, xf_ident); UP(obj_kind, kind); UP(obj_material, omat);
-    UP(obj_transform, oxf); UP(obj_interp, ointerp); UP(obj_geom, geom); UP(obj_normals, nrm);
+    // the per-object arrays go to the device straight from the caller's buffers
+    const size_t n_obj = (size_t)N;
+    UP(spheres, sph); UP(xforms, xf); UP(xf_identity, xf_ident);
+    UP(obj_kind, d->obj_kind, n_obj); UP(obj_material, d->obj_material, n_obj);
+    UP(obj_transform, d->obj_transform, n_obj); UP(obj_interp, d->obj_interp, n_obj);
+    UP(obj_geom, d->obj_geom, 9 * n_obj); UP(obj_normals, d->obj_normals, 9 * n_obj);
     UP(materials, mats); UP(lights, lights);
 #undef UP
 
@@ -932,8 +951,10 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
     std::memcpy(s.cam_ul, d->cam_ul, 24); std::memcpy(s.cam_ur, d->cam_ur, 24); std::memcpy(s.ambient, d->ambient, 24);
     // the shading ray of an empty transform table cannot occur: N > 0 implies NX > 0
 
+    lap("form choice + small uploads");
     // triangle records, groups and the scene header, in the form chosen above
     if (int rc = install_filter(c, c->auto_robust)) return bail(rc);
+    lap("install_filter");
     hipError_t e = c->own_frame.alloc((size_t)d->width * d->height);
     if (e != hipSuccess) return bail(fail(RT_ERR_DEVICE, std::string("frame: ") + hipGetErrorString(e)));
     c->frame = c->own_frame.p;
