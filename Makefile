@@ -16,7 +16,7 @@ hip: $(PKG)/libraytracer_amd.so
 cli: $(PKG)/rt_render
 
 $(PKG)/librt_host.so: $(HOST_SRC) include/rt_host.h include/rt_abi.h
-	$(CXX) -O2 -std=c++17 -ffp-contract=off -fPIC -shared -Iinclude -o $@ $(HOST_SRC) -lz
+	$(CXX) -O2 -std=c++17 -ffp-contract=off -fPIC -shared -Iinclude -o $@ $(HOST_SRC) -lz -pthread
 
 # -ffp-contract=off: the reference-precision device code must not fuse a*b+c;
 # the FP32 filter asks for its FMAs explicitly.

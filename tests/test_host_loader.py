@@ -91,3 +91,18 @@ def test_png_writer_round_trip(tmp_path):
     write_png(str(p), img.tobytes(), 53, 37)
     back = oracle_api.load_png(str(p))
     assert np.array_equal(back, img)
+
+
+def test_png_writer_bands_round_trip(tmp_path):
+    """The PNG writer deflates bands of rows on several threads and joins them into one zlib
+    stream; sizes around the band boundaries (64-row minimum, 16 bands) must decode to the input."""
+    import numpy as np
+    from raytracer_amd import write_png
+    from tests import oracle_api
+    rng = np.random.default_rng(3)
+    for w, h in ((1, 1), (7, 63), (7, 64), (5, 127), (33, 128), (16, 1025), (64, 2161)):
+        img = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+        img[: h // 2] = (img[: h // 2] // 64) * 64          # half compressible, half noise
+        path = os.path.join(str(tmp_path), f"t_{w}x{h}.png")
+        write_png(path, img.tobytes(), w, h)
+        assert np.array_equal(oracle_api.load_png(path), img), (w, h)
