@@ -36,6 +36,6 @@ clean:
 
 # instruction-rate microbenchmarks behind the numbers quoted for the filter kernel
 microbench:
-	for b in microbench microbench2 microbench3 microbench4; do $(HIPCC) --offload-arch=gfx950 -O3 -o tools/$$b tools/$$b.hip || exit 1; done
+	for b in microbench microbench2 microbench3 microbench4 microbench5; do $(HIPCC) --offload-arch=gfx950 -O3 -o tools/$$b tools/$$b.hip || exit 1; done
 
 .PHONY: all host hip cli oracle clean microbench
