@@ -180,3 +180,25 @@ def test_random_scene_against_the_oracle(family, oracle, tmp_path):
     assert worst <= 4 and frac1 >= 0.999 and ndiff <= 3, (worst, ndiff, frac1)
     for key in ("rays_reflect", "rays_shadow", "hits"):
         assert st[key] == c[key], key
+
+
+@pytest.mark.parametrize("eps", [1e-7, 1e-3, 0.5])
+@pytest.mark.parametrize("family", ["soup", "coplanar", "transformed"])
+def test_unusual_epsilons(family, eps, tmp_path):
+    """The filter's thresholds are derived from Scene::eps: a tiny eps leaves nothing certain
+    about grazing rays (the static form then sends every triangle to the reference-precision
+    test), a large one rejects nearby hits.  Every configuration must still equal exact-only."""
+    path = os.path.join(str(tmp_path), "fuzz.scene")
+    with open(path, "w") as f:
+        f.write(random_scene(4242 + FAMILIES.index(family), family))
+    sc = Scene.load(path, 64, 36, 3, eps=eps)
+    want, sw = render(sc, EXACT_ONLY=1)
+    in_plane = 0
+    for opts in ({}, {"FILTER_FORM": 1}, {"FILTER_FORM": 2}, {"FILTER_FORM": 2, "USE_BVH": 1}):
+        if opts.get("USE_BVH") and in_plane:
+            continue                       # the LBVH cannot see in-plane-origin hits (counted by brute force)
+        img, st = render(sc, **opts)
+        in_plane = max(in_plane, st["in_plane_origin_hits"])
+        assert np.array_equal(img, want), (opts, int((img != want).any(axis=-1).sum()))
+        for key in ("rays_reflect", "rays_shadow", "hits"):
+            assert st[key] == sw[key], (key, opts)
