@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <unordered_map>
 #include <string.h>
 
@@ -777,6 +778,7 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
     std::vector<HostTri>& tris = c->h_tris;
     std::vector<SphereRec> sph;
     c->h_slot.assign(N, -1);
+    std::vector<int> tri_objects;            // Scene::objects indices of the triangles, in order
     for (int i = 0; i < N; i++) {
         const double* g = d->obj_geom + 9 * (size_t)i;
         if (d->obj_kind[i] == 1) {
@@ -787,8 +789,16 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
             s.obj = i; s.xf = d->obj_transform[i]; s.identity = xf_ident[s.xf];
             c->h_slot[i] = (int32_t)sph.size();
             sph.push_back(s);
-            continue;
+        } else {
+            tri_objects.push_back(i);
         }
+    }
+    tris.assign(tri_objects.size(), HostTri{});
+    // one record per triangle, independent of the others: large meshes are spread over host threads
+    auto build_records = [&](size_t k_begin, size_t k_end) {
+      for (size_t k_tri = k_begin; k_tri < k_end; k_tri++) {
+        const int i = tri_objects[k_tri];
+        const double* g = d->obj_geom + 9 * (size_t)i;
         HostTri t{};
         t.xf = d->obj_transform[i];
         Vec v1{g[0], g[1], g[2]}, v2{g[3], g[4], g[5]}, v3{g[6], g[7], g[8]};
@@ -877,7 +887,22 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
                 }
             }
         }
-        tris.push_back(t);
+        tris[k_tri] = t;
+      }
+    };
+    {
+        const size_t n_tri = tri_objects.size();
+        const unsigned hw = std::thread::hardware_concurrency();
+        const size_t n_threads = n_tri < 65536 ? 1 : std::min<size_t>(16, std::max(1u, hw));
+        if (n_threads <= 1) {
+            build_records(0, n_tri);
+        } else {
+            std::vector<std::thread> pool;
+            const size_t per = (n_tri + n_threads - 1) / n_threads;
+            for (size_t t0 = 0; t0 < n_tri; t0 += per)
+                pool.emplace_back(build_records, t0, std::min(n_tri, t0 + per));
+            for (auto& th : pool) th.join();
+        }
     }
     c->h_xf_ident = xf_ident;
     c->h_xf = xf;

@@ -223,6 +223,29 @@ def test_edge_cases():
     r.close()
 
 
+def test_more_than_32_lights(oracle, tmp_path):
+    """Occlusion bits take one 32-bit word per 32 lights: 40 point and directional lights over a
+    small mesh and a sphere, brute force and LBVH, against the oracle."""
+    lines = ["cam 0 1 8  -3.2 -1.4 4  3.2 -1.4 4  -3.2 2.2 4  3.2 2.2 4", "lta 0.05 0.05 0.05"]
+    for k in range(40):
+        ang = 2 * np.pi * k / 40
+        if k % 5 == 4:
+            lines.append(f"ltd {np.cos(ang):.4f} -1 {np.sin(ang):.4f}  0.03 0.03 0.03")
+        else:
+            lines.append(f"ltp {6 * np.cos(ang):.4f} {3 + (k % 3)} {6 * np.sin(ang):.4f}  0.06 0.05 0.04  {k % 3}")
+    lines += ["mat 0.1 0.1 0.1  0.6 0.5 0.4  0.5 0.5 0.5  20  0.3 0.3 0.3", "sph -1.2 0.4 0.5 0.7",
+              "xft 1.0 0 0", "xfs 0.8 0.8 0.8", "obj %s" % os.path.join(ROOT, "scenes", "dodec.obj"), "xfz",
+              "tri -6 -1 -6  -6 -1 6  6 -1 6", "tri -6 -1 -6  6 -1 6  6 -1 -6"]
+    path = os.path.join(str(tmp_path), "lights.scene")
+    open(path, "w").write("\n".join(lines) + "\n")
+    sc = Scene.load(path, 96, 72, 3)
+    want, c = oracle.render(sc, threads=16)
+    for bvh in (False, True):
+        img, st = gpu_render(sc, bvh=bvh)
+        assert_parity(img, want, max_diff_pixels=3)
+        assert st["rays_shadow"] == c["rays_shadow"] == 40 * c["hits"]
+
+
 def test_cli_driver_writes_the_reference_image(tmp_path):
     """The C++ host driver (the reference's main) end to end: scene file -> PNG."""
     import subprocess
