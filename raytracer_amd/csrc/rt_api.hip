@@ -1058,6 +1058,7 @@ int rt_primary_hits(rt_ctx* c, int y0, int rows, uint64_t* keys, size_t count) {
     const int W = c->hs.width;
     if (count < (size_t)rows * W) return fail(RT_ERR_RANGE, "rt_primary_hits: buffer too small");
     HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());          // renders still in flight on other streams use the same workspace
     int rc = ensure_workspace(c);
     if (rc) return rc;
     const int rows_per_pass = (int)(c->cap / W);
