@@ -320,7 +320,7 @@ int launch_trace(rt_ctx* c, TraceArgs A, hipStream_t st, bool camera_rays = fals
         t.stop();
     }
     Timed t(c, st, 2);
-    if (!c->force_exact && c->hs.n_regular > 0) {
+    if (!c->force_exact && c->hs.n_regular > 0 && !c->use_bvh) {      // (the LBVH traversal lists no pairs)
         hipLaunchKernelGGL(k_exact_pairs<MODE>, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, dsc,
                            (const TriExact*)c->tri_exact.p, A);
         HIP_TRY(hipGetLastError());
