@@ -33,9 +33,22 @@ oracle:
 
 clean:
 	rm -f $(PKG)/*.so $(PKG)/rt_render oracle/*.so
+	rm -rf asan_build
 
 # instruction-rate microbenchmarks behind the numbers quoted for the filter kernel
 microbench:
 	for b in microbench microbench2 microbench3 microbench4 microbench5; do $(HIPCC) --offload-arch=gfx950 -O3 -o tools/$$b tools/$$b.hip || exit 1; done
 
-.PHONY: all host hip cli oracle clean microbench
+# Host-side AddressSanitizer build of both libraries and the driver into asan_build/
+# (device code is not instrumented).  tools/asan_cli.sh runs it; delete the directory
+# afterwards, it is uploaded with every GPU call while it exists.
+ASANXX ?= /opt/rocm/lib/llvm/bin/amdclang++
+asan:
+	mkdir -p asan_build
+	$(HIPCC) --offload-arch=gfx950 -O1 -g -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -Xarch_host -fsanitize=address \
+	  -Iinclude -I$(PKG)/csrc -o asan_build/libraytracer_amd.so $(HIP_SRC)
+	$(ASANXX) -O1 -g -std=c++17 -ffp-contract=off -fsanitize=address -fPIC -shared -Iinclude -o asan_build/librt_host.so $(HOST_SRC) -lz -pthread
+	$(ASANXX) -O1 -g -std=c++17 -fsanitize=address -Iinclude -o asan_build/rt_render $(PKG)/host/rt_cli.cpp -Lasan_build -lrt_host -lraytracer_amd \
+	  -Wl,-rpath,'$$ORIGIN' -Wl,-rpath-link,/opt/rocm/lib
+
+.PHONY: all host hip cli oracle clean microbench asan
