@@ -19,10 +19,19 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <memory>
+#include <utility>
 #include <fstream>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace {
 
@@ -100,10 +109,20 @@ bool same_bits(const void* p, const void* q, size_t n) { return std::memcmp(p, q
 
 }  // namespace
 
+// resize(n) of a vector with this allocator leaves new elements uninitialised (and their
+// pages untouched), so the threads that fill a large array are the first to touch it.
+template <class T> struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    template <class U, class... A> void construct(U* p, A&&... a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void*)p) U;
+        else ::new ((void*)p) U(std::forward<A>(a)...);
+    }
+};
+
 struct rth_scene {
     rt_scene_desc d{};
     std::vector<int32_t> kind, material, transform, interp;
-    std::vector<double> geom, normals;
+    std::vector<double, NoInitAlloc<double>> geom, normals;
     std::vector<rt_material> materials;
     std::vector<rt_transform> transforms;
     std::vector<rt_light> lights;
@@ -180,10 +199,141 @@ struct Builder {
     int load_obj(const std::string& name);
 };
 
+// ---- .obj files -------------------------------------------------------------------
+// parseObj (raytracer.cpp:624-703) reads a line, splits it at white space and looks at
+// the first token; the text of a mesh with a million faces is tens of megabytes, so the
+// file is mapped, cut at line ends into chunks and the chunks are parsed concurrently.
+// A face may only name vertices that stand before it in the file (anything else is out of
+// range in the reference), so every face remembers how many vertices and normals its own
+// chunk had seen; the chunks' totals give the rest once all of them are parsed, and the
+// faces are then resolved straight into the scene's arrays, again chunk by chunk.
+
+inline bool is_blank(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
+
+// One white-space separated token of [p, end); false at the end of the line.
+inline bool next_token(const char*& p, const char* end, const char*& tb, const char*& te) {
+    while (p < end && is_blank(*p)) p++;
+    if (p >= end) return false;
+    tb = p;
+    while (p < end && !is_blank(*p)) p++;
+    te = p;
+    return true;
+}
+
+// The token as a C string (atof / atol want a terminator; the mapped file has none).
+struct TokenText {
+    char small[64];
+    std::string big;
+    const char* get(const char* b, const char* e) {
+        const size_t n = (size_t)(e - b);
+        if (n < sizeof small) { std::memcpy(small, b, n); small[n] = 0; return small; }
+        big.assign(b, e);
+        return big.c_str();
+    }
+};
+
+struct ObjFace {
+    long vi[3], ni[3];
+    long verts_before, norms_before;   // entries of this chunk's own arrays that precede the face
+    bool with_normals;
+};
+
+struct ObjChunk {
+    const char* begin = nullptr;
+    const char* end = nullptr;
+    std::vector<double> verts, norms;
+    std::vector<ObjFace> faces;
+    std::vector<unsigned char> messages;   // 0 unknown input, 1 vertex count, 2 normal count; file order
+    long verts_base = 0, norms_base = 0;   // entries of earlier chunks
+    size_t first_object = 0;
+};
+
+void parse_obj_chunk(ObjChunk& c) {
+    TokenText text;
+    const char* line = c.begin;
+    while (line < c.end) {
+        const char* eol = (const char*)std::memchr(line, '\n', (size_t)(c.end - line));
+        if (!eol) eol = c.end;
+        const char* p = line;
+        const char *tb, *te;
+        line = eol + 1;
+        if (!next_token(p, eol, tb, te)) continue;                       // empty or blank line
+        const size_t len = (size_t)(te - tb);
+        if (len == 1 && *tb == '#') continue;
+        const bool is_v = len == 1 && *tb == 'v';
+        const bool is_vn = len == 2 && tb[0] == 'v' && tb[1] == 'n';
+        if (is_v || is_vn) {
+            float a[3] = {0.f, 0.f, 0.f};
+            int n = 0;
+            while (next_token(p, eol, tb, te)) {
+                if (n < 3) a[n] = (float)atof(text.get(tb, te));
+                n++;
+            }
+            if (n != 3) c.messages.push_back(is_v ? 1 : 2);
+            std::vector<double>& dst = is_v ? c.verts : c.norms;
+            for (int i = 0; i < 3; i++) dst.push_back((double)a[i]);
+        } else if (len == 1 && *tb == 'f') {
+            ObjFace f{};
+            f.verts_before = (long)(c.verts.size() / 3);
+            f.norms_before = (long)(c.norms.size() / 3);
+            int n = 0;
+            while (next_token(p, eol, tb, te)) {
+                const char* sep = nullptr;                               // first "//" of the token
+                for (const char* q = tb; q + 1 < te; q++)
+                    if (q[0] == '/' && q[1] == '/') { sep = q; break; }
+                f.with_normals = sep != nullptr;                         // the LAST token decides (raytracer.cpp:658)
+                if (n < 3) {
+                    if (sep) {
+                        f.vi[n] = atol(text.get(tb, sep));
+                        f.ni[n] = atol(text.get(sep + 2, te));
+                    } else {
+                        f.vi[n] = atol(text.get(tb, te));
+                    }
+                }
+                n++;
+            }
+            c.faces.push_back(f);
+        } else {
+            c.messages.push_back(0);
+        }
+    }
+}
+
+struct MappedFile {
+    const char* data = nullptr;
+    size_t size = 0;
+    bool ok = false;
+    explicit MappedFile(const std::string& path) {
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return;
+        struct stat st;
+        if (::fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) {
+            size = (size_t)st.st_size;
+            ok = true;
+            if (size) {
+                void* m = ::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m == MAP_FAILED) { ok = false; size = 0; } else data = (const char*)m;
+            }
+        }
+        ::close(fd);
+    }
+    ~MappedFile() { if (data) ::munmap((void*)data, size); }
+    MappedFile(const MappedFile&) = delete;
+    MappedFile& operator=(const MappedFile&) = delete;
+};
+
+template <class F> void for_chunks(size_t n, int n_threads, F&& body) {
+    if (n_threads <= 1 || n <= 1) { for (size_t k = 0; k < n; k++) body(k); return; }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < n_threads; t++)
+        pool.emplace_back([&, t]() { for (size_t k = (size_t)t; k < n; k += (size_t)n_threads) body(k); });
+    for (auto& th : pool) th.join();
+}
+
 int Builder::load_obj(const std::string& name) {
     std::string path = (name.empty() || name[0] == '/' || dir.empty()) ? name : dir + "/" + name;
-    std::ifstream f(path);
-    if (!f.is_open()) {
+    MappedFile file(path);
+    if (!file.ok) {
         fprintf(stderr, "Error opening obj file\n");   // the reference carries on (raytracer.cpp:632-635)
         return 0;
     }
@@ -191,47 +341,80 @@ int Builder::load_obj(const std::string& name) {
     int xf = transform_id(&ok);
     if (!ok) return fail(RT_ERR_ARG, "singular transform in front of obj " + name);
     int mat = material_id();
-    std::vector<double> verts(3, 0.0), norms(3, 0.0);   // index 0 is a dummy: OBJ indices start at 1
-    std::string line, cmd;
-    while (std::getline(f, line)) {
-        std::istringstream iss(line);
-        if (line.empty() || !(iss >> cmd) || cmd == "#") continue;
-        if (cmd == "v" || cmd == "vn") {
-            float a[3];
-            read_floats(iss, a, 3, cmd == "v" ? "vertex in obj file." : "vertex normal in obj file.");
-            std::vector<double>& dst = (cmd == "v") ? verts : norms;
-            for (int i = 0; i < 3; i++) dst.push_back((double)a[i]);
-        } else if (cmd == "f") {
-            long vi[3] = {0, 0, 0}, ni[3] = {0, 0, 0};
-            bool with_normals = false;   // decided by the LAST token, as in raytracer.cpp:658
-            std::string tok;
-            int n = 0;
-            while (iss >> tok) {
-                size_t pos = tok.find("//");
-                with_normals = pos != std::string::npos;
-                if (n < 3) {
-                    if (with_normals) {
-                        vi[n] = atol(tok.substr(0, pos).c_str());
-                        ni[n] = atol(tok.substr(pos + 2).c_str());
-                    } else {
-                        vi[n] = atol(tok.c_str());
-                    }
-                }
-                n++;
-            }
-            double g[9], nn[9];
-            long nv = (long)verts.size() / 3, nnrm = (long)norms.size() / 3;
-            for (int k = 0; k < 3; k++) {
-                bool in = vi[k] >= 0 && vi[k] < nv;     // out of range is undefined in the reference
-                for (int c = 0; c < 3; c++) g[3 * k + c] = in ? verts[3 * vi[k] + c] : 0.0;
-                bool inn = ni[k] >= 0 && ni[k] < nnrm;
-                for (int c = 0; c < 3; c++) nn[3 * k + c] = inn ? norms[3 * ni[k] + c] : 0.0;
-            }
-            add_object(0, g, with_normals ? nn : nullptr, mat, xf);
-        } else {
-            fprintf(stderr, "Unknown input in obj file: %s.\n", path.c_str());
+
+    // chunks of about 1 MiB (RTH_OBJ_CHUNK_BYTES overrides, for tests), each ending after a line end
+    const unsigned hw = std::thread::hardware_concurrency();
+    size_t chunk_bytes = (size_t)1 << 20;
+    if (const char* e = getenv("RTH_OBJ_CHUNK_BYTES")) chunk_bytes = std::max<size_t>(1, (size_t)atoll(e));
+    const size_t n_chunks_want = std::max<size_t>(1, file.size / chunk_bytes);
+    const int n_threads = (int)std::min<size_t>(std::min<size_t>(16, hw ? hw : 4), n_chunks_want);
+    std::vector<ObjChunk> chunks;
+    const char* at = file.data;
+    const char* const file_end = file.data + file.size;
+    for (size_t k = 0; k < n_chunks_want && at < file_end; k++) {
+        const char* stop = file_end;
+        if (k + 1 < n_chunks_want) {
+            const char* want = file.data + file.size / n_chunks_want * (k + 1);
+            if (want < at) want = at;
+            const char* nl = (const char*)std::memchr(want, '\n', (size_t)(file_end - want));
+            stop = nl ? nl + 1 : file_end;
         }
+        ObjChunk c;
+        c.begin = at; c.end = stop;
+        chunks.push_back(std::move(c));
+        at = stop;
     }
+    for_chunks(chunks.size(), n_threads, [&](size_t k) { parse_obj_chunk(chunks[k]); });
+
+    // messages in file order, as the reference prints them while it reads
+    for (const ObjChunk& c : chunks)
+        for (unsigned char m : c.messages) {
+            if (m == 0) fprintf(stderr, "Unknown input in obj file: %s.\n", path.c_str());
+            else fprintf(stderr, "Incorrect number of arguments for %s\n", m == 1 ? "vertex in obj file." : "vertex normal in obj file.");
+        }
+
+    // index 0 of the vertex and normal arrays is a dummy: OBJ indices start at 1
+    long n_verts = 1, n_norms = 1;
+    size_t n_faces = 0;
+    for (ObjChunk& c : chunks) {
+        c.verts_base = n_verts; c.norms_base = n_norms; c.first_object = s->kind.size() + n_faces;
+        n_verts += (long)(c.verts.size() / 3); n_norms += (long)(c.norms.size() / 3);
+        n_faces += c.faces.size();
+    }
+    std::vector<double> verts((size_t)n_verts * 3, 0.0), norms((size_t)n_norms * 3, 0.0);
+    const size_t total = s->kind.size() + n_faces;
+    if (total > s->kind.capacity()) {                                   // room for what the scene file adds later
+        const size_t cap = total + total / 16 + 1024;
+        s->kind.reserve(cap); s->material.reserve(cap); s->transform.reserve(cap); s->interp.reserve(cap);
+        s->geom.reserve(cap * 9); s->normals.reserve(cap * 9);
+    }
+    s->kind.resize(total, 0);
+    s->material.resize(total, mat);
+    s->transform.resize(total, xf);
+    s->interp.resize(total, 0);
+    s->geom.resize(total * 9);                                          // every element is written below
+    s->normals.resize(total * 9);
+    for_chunks(chunks.size(), n_threads, [&](size_t k) {
+        const ObjChunk& c = chunks[k];
+        if (!c.verts.empty()) std::memcpy(&verts[(size_t)c.verts_base * 3], c.verts.data(), c.verts.size() * sizeof(double));
+        if (!c.norms.empty()) std::memcpy(&norms[(size_t)c.norms_base * 3], c.norms.data(), c.norms.size() * sizeof(double));
+    });
+    for_chunks(chunks.size(), n_threads, [&](size_t k) {
+        const ObjChunk& c = chunks[k];
+        for (size_t j = 0; j < c.faces.size(); j++) {
+            const ObjFace& f = c.faces[j];
+            const long nv = c.verts_base + f.verts_before, nn = c.norms_base + f.norms_before;
+            double* g = &s->geom[(c.first_object + j) * 9];
+            double* nrm = &s->normals[(c.first_object + j) * 9];
+            for (int v = 0; v < 3; v++) {
+                const bool in = f.vi[v] >= 0 && f.vi[v] < nv;           // out of range is undefined in the reference
+                for (int x = 0; x < 3; x++) g[3 * v + x] = in ? verts[3 * (size_t)f.vi[v] + x] : 0.0;
+                const bool inn = f.with_normals && f.ni[v] >= 0 && f.ni[v] < nn;
+                for (int x = 0; x < 3; x++) nrm[3 * v + x] = inn ? norms[3 * (size_t)f.ni[v] + x] : 0.0;
+            }
+            s->interp[c.first_object + j] = f.with_normals ? 1 : 0;
+        }
+    });
     return 0;
 }
 

@@ -150,3 +150,88 @@ def test_loader_survives_malformed_input(tmp_path):
         again = Scene.load_blob(blob)
         assert again.desc.n_objects == sc.desc.n_objects
     assert loaded > 0
+
+
+def _model_obj_parse(text):
+    """Line-by-line model of the .obj grammar the loader accepts (raytracer.cpp:624-703):
+    first token decides; numbers go text -> atof -> float; a face takes its first three tokens,
+    the last token decides whether it carries normals; an index that does not name an
+    earlier vertex reads as (0, 0, 0)."""
+    import re
+    num = re.compile(r"^[+-]?(\d+\.?\d*([eE][+-]?\d+)?|\.\d+([eE][+-]?\d+)?)")
+
+    def atof(tok):
+        m = num.match(tok)
+        with np.errstate(over="ignore"):                             # 80 digits: atof -> 1e79 -> float inf
+            return float(np.float32(float(m.group(0)))) if m else 0.0
+
+    def atol(tok):
+        m = re.match(r"^[+-]?\d+", tok)
+        return int(m.group(0)) if m else 0
+
+    verts, norms, faces = [(0.0, 0.0, 0.0)], [(0.0, 0.0, 0.0)], []
+    for line in text.split("\n"):
+        toks = line.replace("\r", " ").replace("\t", " ").split(" ")
+        toks = [t for t in toks if t]
+        if not toks or toks[0] == "#":
+            continue
+        if toks[0] in ("v", "vn"):
+            a = [atof(t) for t in toks[1:4]] + [0.0] * 3
+            (verts if toks[0] == "v" else norms).append(tuple(a[:3]))
+        elif toks[0] == "f":
+            vi, ni, with_n = [0, 0, 0], [0, 0, 0], False
+            for n, t in enumerate(toks[1:]):
+                pos = t.find("//")
+                with_n = pos >= 0
+                if n < 3:
+                    if with_n:
+                        vi[n], ni[n] = atol(t[:pos]), atol(t[pos + 2:])
+                    else:
+                        vi[n] = atol(t)
+            g = [verts[i] if 0 <= i < len(verts) else (0.0, 0.0, 0.0) for i in vi]
+            nn = [norms[i] if with_n and 0 <= i < len(norms) else (0.0, 0.0, 0.0) for i in ni]
+            faces.append((sum(map(list, g), []), sum(map(list, nn), []), int(with_n)))
+    return faces
+
+
+def test_obj_chunks_parse_like_one_pass(tmp_path, monkeypatch):
+    # The .obj text is cut at line ends and parsed concurrently; faces may name vertices of
+    # earlier chunks, must not see later ones, and come out in file order.
+    lines = ["# head", "#tight", "v 0 0 0", "v 1 0 0\r", "v\t0\t1\t0", "v 1 2", "v 1 2 3 4", "vn 0 0 1", "vn 0 1",
+             "f 1 2 3", "f 1//1 2//2 3//", "f //1 2 3", "f 1/2/3 2/5/6 3/8/9 10", "f 1//1 2//2 3", "f 1 2 3//1",
+             "f 7 8 9", "f -1 2 3", "f 1 2", "f", "   ", "", "\r", "v 1e-3 +2 -.5", "v 1.5abc 2,3 4", "g group",
+             "v " + "1" * 80 + " 2 3", "f 3 2 1 # trailing", "\tf 1 2 3", "f 1\t2\t3\t"]
+    for k in range(1500):
+        lines.append(f"v {k * 0.001:.4f} {k % 7} {-k}")
+        if k % 3 == 2:
+            lines.append(f"f {k} {k + 1} {k + 2}")                   # k + 2 is not defined yet
+        if k % 50 == 0:
+            lines += ["vn 0 1 0", f"f {k}//{k // 50} {k - 1}//1 {k - 2}//2"]
+        if k % 97 == 0:
+            lines.append("bogus line")
+    text = "\n".join(lines) + "\nf 1 2 3"                            # no newline at the end
+    (tmp_path / "m.obj").write_text(text, newline="")
+    (tmp_path / "s.scene").write_text(
+        "cam 0 0 2 -1 -1 1 1 -1 1 -1 1 1 1 1 1\nmat .1 .1 .1 1 1 1 0 0 0 1 0 0 0\nsph 0 0 0 1\nobj m.obj\nsph 1 1 1 2\n")
+    model = _model_obj_parse(text)
+    blobs = []
+    for chunk in (None, "64", "1000", "20000"):
+        if chunk is None:
+            monkeypatch.delenv("RTH_OBJ_CHUNK_BYTES", raising=False)
+        else:
+            monkeypatch.setenv("RTH_OBJ_CHUNK_BYTES", chunk)
+        sc = Scene.load(str(tmp_path / "s.scene"), 8, 8)
+        out = tmp_path / f"c{chunk}.rtsd"
+        sc.save_blob(str(out))
+        blobs.append(out.read_bytes())
+        d = sc.desc
+        assert d.n_objects == len(model) + 2
+        geom = np.ctypeslib.as_array(d.obj_geom, shape=(d.n_objects, 9))
+        nrm = np.ctypeslib.as_array(d.obj_normals, shape=(d.n_objects, 9))
+        kinds = [d.obj_kind[i] for i in (0, d.n_objects - 1)]
+        assert kinds == [1, 1]                                       # the spheres stand before and after the mesh
+        for j, (g, n, w) in enumerate(model):
+            assert geom[1 + j].tolist() == g, (chunk, j)
+            assert nrm[1 + j].tolist() == n, (chunk, j)
+            assert d.obj_interp[1 + j] == w, (chunk, j)
+    assert all(b == blobs[0] for b in blobs)
