@@ -65,6 +65,22 @@ struct Box {
 
 double max_abs(Vec p) { return std::max(std::fabs(p.x), std::max(std::fabs(p.y), std::fabs(p.z))); }
 
+// body(part, begin, end) over [0, n) cut into equal parts, one host thread per part; a single
+// inline call when n is small.  Returns the number of parts (indices 0 .. parts-1 were used).
+inline size_t host_parts(size_t n) {
+    if (n < 65536) return 1;
+    const unsigned hw = std::thread::hardware_concurrency();
+    return std::min<size_t>(16, std::max(1u, hw));
+}
+template <class F> void parallel_ranges(size_t n, size_t parts, F&& body) {
+    if (parts <= 1) { body((size_t)0, (size_t)0, n); return; }
+    std::vector<std::thread> pool;
+    const size_t per = (n + parts - 1) / parts;
+    for (size_t k = 0; k < parts; k++)
+        pool.emplace_back([&body, k, per, n]() { body(k, std::min(n, k * per), std::min(n, (k + 1) * per)); });
+    for (auto& th : pool) th.join();
+}
+
 template <class T> struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
@@ -501,26 +517,39 @@ int install_filter(rt_ctx* c, int robust) {
     HIP_TRY(hipDeviceSynchronize());          // no launch may still read the records replaced here
     const std::vector<HostTri>& tris = c->h_tris;
     auto regular = [&](const HostTri& t) { return robust ? t.ok_robust : t.ok_static; };
+    // regular triangles by (transform, dominant axis), irregular ones by transform, file order
+    // within a key: a counting sort, the keys are few
     std::vector<int> order_reg, order_irr;
-    for (int k = 0; k < (int)tris.size(); k++) (regular(tris[k]) ? order_reg : order_irr).push_back(k);
-    auto by_xf = [&](int a, int b) { return tris[a].xf < tris[b].xf; };
-    auto by_xf_axis = [&](int a, int b) {
-        return tris[a].xf != tris[b].xf ? tris[a].xf < tris[b].xf : tris[a].axis < tris[b].axis;
-    };
-    std::stable_sort(order_reg.begin(), order_reg.end(), by_xf_axis);
-    std::stable_sort(order_irr.begin(), order_irr.end(), by_xf);
+    {
+        int n_xf = 1;
+        for (const HostTri& t : tris) n_xf = std::max(n_xf, t.xf + 1);
+        std::vector<size_t> n_reg((size_t)n_xf * 3 + 1, 0), n_irr((size_t)n_xf + 1, 0);
+        for (const HostTri& t : tris) {
+            if (regular(t)) n_reg[(size_t)t.xf * 3 + t.axis + 1]++; else n_irr[(size_t)t.xf + 1]++;
+        }
+        for (size_t k = 1; k < n_reg.size(); k++) n_reg[k] += n_reg[k - 1];
+        for (size_t k = 1; k < n_irr.size(); k++) n_irr[k] += n_irr[k - 1];
+        order_reg.resize(n_reg.back()); order_irr.resize(n_irr.back());
+        for (int k = 0; k < (int)tris.size(); k++) {
+            const HostTri& t = tris[k];
+            if (regular(t)) order_reg[n_reg[(size_t)t.xf * 3 + t.axis]++] = k; else order_irr[n_irr[(size_t)t.xf]++] = k;
+        }
+    }
     const int NR = (int)order_reg.size(), NI = (int)order_irr.size();
+    const size_t parts = host_parts(tris.size());
     std::vector<v16f> filt((size_t)NR + 1);          // + one readable padding record
-    std::memset(filt.data(), 0, filt.size() * sizeof(v16f));
+    std::memset(&filt[NR], 0, sizeof(v16f));
     std::vector<TriExact> exact((size_t)NR + NI);
     std::vector<int32_t>& slot = c->h_slot;
-    for (int k = 0; k < NR; k++) {
-        const HostTri& t = tris[order_reg[k]];
-        const float* f = robust ? t.f_robust : t.f_static;
-        for (int j = 0; j < 16; j++) filt[k][j] = f[j];
-        exact[k] = t.ex;
-        slot[t.ex.obj] = k;
-    }
+    parallel_ranges((size_t)NR, parts, [&](size_t, size_t k0, size_t k1) {
+        for (size_t k = k0; k < k1; k++) {
+            const HostTri& t = tris[order_reg[k]];
+            const float* f = robust ? t.f_robust : t.f_static;
+            for (int j = 0; j < 16; j++) filt[k][j] = f[j];
+            exact[k] = t.ex;
+            slot[t.ex.obj] = (int32_t)k;
+        }
+    });
     for (int k = 0; k < NI; k++) {
         const HostTri& t = tris[order_irr[k]];
         exact[(size_t)NR + k] = t.ex;
@@ -576,11 +605,14 @@ int install_filter(rt_ctx* c, int robust) {
         const Vec eye{c->hs.cam_eye[0], c->hs.cam_eye[1], c->hs.cam_eye[2]};
         for (const Group& G : groups) {
             const Vec o = G.identity ? eye : affine_point(&c->h_xf[48 * (size_t)G.xf + 16], eye);
-            for (int k = G.fax[0]; k < G.fax[3]; k++) {
-                const TriExact& ex = exact[k];
-                const Vec w0{o.x - ex.v1[0], o.y - ex.v1[1], o.z - ex.v1[2]};
-                eye_a[k] = (float)(-(ex.n[0] * w0.x + ex.n[1] * w0.y + ex.n[2] * w0.z));
-            }
+            const size_t first = (size_t)G.fax[0], count = (size_t)(G.fax[3] - G.fax[0]);
+            parallel_ranges(count, host_parts(count), [&](size_t, size_t k0, size_t k1) {
+                for (size_t k = first + k0; k < first + k1; k++) {
+                    const TriExact& ex = exact[k];
+                    const Vec w0{o.x - ex.v1[0], o.y - ex.v1[1], o.z - ex.v1[2]};
+                    eye_a[k] = (float)(-(ex.n[0] * w0.x + ex.n[1] * w0.y + ex.n[2] * w0.z));
+                }
+            });
         }
         std::vector<int32_t> row(std::max<size_t>(c->h_lights.size(), 1), -1);
         std::vector<float> rinv;
@@ -595,10 +627,12 @@ int install_filter(rt_ctx* c, int robust) {
             row[l] = n_rows++;
             rinv.resize((size_t)n_rows * ((size_t)NR + 1), 0.f);
             float* out = &rinv[(size_t)row[l] * ((size_t)NR + 1)];
-            for (int k = 0; k < NR; k++) {
-                const TriExact& ex = exact[k];
-                out[k] = (float)(1.0 / (ex.n[0] * dir.x + ex.n[1] * dir.y + ex.n[2] * dir.z));
-            }
+            parallel_ranges((size_t)NR, parts, [&](size_t, size_t k0, size_t k1) {
+                for (size_t k = k0; k < k1; k++) {
+                    const TriExact& ex = exact[k];
+                    out[k] = (float)(1.0 / (ex.n[0] * dir.x + ex.n[1] * dir.y + ex.n[2] * dir.z));
+                }
+            });
         }
         HIP_TRY(c->eye_a.upload(eye_a));
         HIP_TRY(c->light_dir_row.upload(row));
@@ -686,22 +720,38 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
     Box world;
     world.add({d->cam_eye[0], d->cam_eye[1], d->cam_eye[2]});
     std::vector<double> xf_extent(std::max(NX, 1), 0.0);   // largest |coordinate| of a transform's object-space vertices
-    for (int i = 0; i < N; i++) {
-        const double* g = d->obj_geom + 9 * (size_t)i;
-        const double* M = &xf[48 * (size_t)d->obj_transform[i]];
-        if (d->obj_kind[i] == 0) {
-            for (int k = 0; k < 3; k++) {
-                Vec v{g[3 * k], g[3 * k + 1], g[3 * k + 2]};
-                world.add(affine_point(M, v));
-                double& ext = xf_extent[d->obj_transform[i]];
-                ext = std::max(ext, max_abs(v));
+    {
+        const size_t parts = host_parts((size_t)N);
+        std::vector<Box> part_box(parts);
+        std::vector<std::vector<double>> part_extent(parts, std::vector<double>(std::max(NX, 1), 0.0));
+        parallel_ranges((size_t)N, parts, [&](size_t part, size_t i0, size_t i1) {
+            Box& box = part_box[part];
+            std::vector<double>& extent = part_extent[part];
+            for (size_t i = i0; i < i1; i++) {
+                const double* g = d->obj_geom + 9 * i;
+                const double* M = &xf[48 * (size_t)d->obj_transform[i]];
+                if (d->obj_kind[i] == 0) {
+                    for (int k = 0; k < 3; k++) {
+                        Vec v{g[3 * k], g[3 * k + 1], g[3 * k + 2]};
+                        box.add(affine_point(M, v));
+                        double& ext = extent[d->obj_transform[i]];
+                        ext = std::max(ext, max_abs(v));
+                    }
+                } else {
+                    double r = std::fabs(g[3]);
+                    for (int k = 0; k < 8; k++) {
+                        Vec v{g[0] + ((k & 1) ? r : -r), g[1] + ((k & 2) ? r : -r), g[2] + ((k & 4) ? r : -r)};
+                        box.add(affine_point(M, v));
+                    }
+                }
             }
-        } else {
-            double r = std::fabs(g[3]);
-            for (int k = 0; k < 8; k++) {
-                Vec v{g[0] + ((k & 1) ? r : -r), g[1] + ((k & 2) ? r : -r), g[2] + ((k & 4) ? r : -r)};
-                world.add(affine_point(M, v));
+        });
+        for (size_t part = 0; part < parts; part++) {
+            for (int a = 0; a < 3; a++) {
+                world.lo[a] = std::min(world.lo[a], part_box[part].lo[a]);
+                world.hi[a] = std::max(world.hi[a], part_box[part].hi[a]);
             }
+            for (int t = 0; t < NX; t++) xf_extent[t] = std::max(xf_extent[t], part_extent[part][t]);
         }
     }
 
@@ -890,20 +940,8 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
         tris[k_tri] = t;
       }
     };
-    {
-        const size_t n_tri = tri_objects.size();
-        const unsigned hw = std::thread::hardware_concurrency();
-        const size_t n_threads = n_tri < 65536 ? 1 : std::min<size_t>(16, std::max(1u, hw));
-        if (n_threads <= 1) {
-            build_records(0, n_tri);
-        } else {
-            std::vector<std::thread> pool;
-            const size_t per = (n_tri + n_threads - 1) / n_threads;
-            for (size_t t0 = 0; t0 < n_tri; t0 += per)
-                pool.emplace_back(build_records, t0, std::min(n_tri, t0 + per));
-            for (auto& th : pool) th.join();
-        }
-    }
+    parallel_ranges(tri_objects.size(), host_parts(tri_objects.size()),
+                    [&](size_t, size_t k0, size_t k1) { build_records(k0, k1); });
     c->h_xf_ident = xf_ident;
     c->h_xf = xf;
     c->scene_bound = R_max;

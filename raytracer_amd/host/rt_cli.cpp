@@ -45,16 +45,22 @@ int main(int argc, char** argv) {
         else { fprintf(stderr, "unexpected argument %s\n", a.c_str()); return 2; }
     }
     printf("Ray Tracer!\n");
+    auto now = []() { return std::chrono::steady_clock::now(); };
+    auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(now() - t).count(); };
+    auto t_load = now();
     rth_scene* sc = nullptr;
     if (rth_load_scene(&sc, scene.c_str(), width, height, depth, eps)) {
         fprintf(stderr, "%s\n", rth_last_error());
         return 1;
     }
+    const double load_s = since(t_load);
+    auto t_upload = now();
     rt_ctx* ctx = nullptr;
     if (rt_upload_scene(&ctx, rth_desc(sc))) {
         fprintf(stderr, "%s\n", rt_last_error());
         return 1;
     }
+    const double upload_s = since(t_upload);
     if (exact && rt_set_option(ctx, RT_OPT_EXACT_ONLY, 1)) { fprintf(stderr, "%s\n", rt_last_error()); return 1; }
     if (bvh && rt_set_option(ctx, RT_OPT_USE_BVH, 1)) { fprintf(stderr, "%s\n", rt_last_error()); return 1; }
     printf("Rendering Scene...\n");
@@ -77,11 +83,14 @@ int main(int argc, char** argv) {
         }
     }
     printf("Writing to file...\n");
+    auto t_png = now();
     if (rth_write_png(out.c_str(), image.data(), width, height)) {
         fprintf(stderr, "cannot write %s\n", out.c_str());
         return 1;
     }
     printf("Image saved as %s.\n", out.c_str());
+    if (stats)   // render_s above covers the trace (any LBVH build included) and the download of the frame
+        printf("{\"load_s\": %.6f, \"upload_s\": %.6f, \"png_s\": %.6f}\n", load_s, upload_s, since(t_png));
     rt_free(ctx);
     rth_free_scene(sc);
     return 0;
