@@ -257,8 +257,6 @@ __device__ __forceinline__ void filter_z2(const v16f f, v2f px, v2f py, v2f pz, 
     const v2f s = __builtin_elementwise_fma(c4, hu, __builtin_elementwise_fma(c5, hv, c6));
     const v2f t = __builtin_elementwise_fma(c7, hu, __builtin_elementwise_fma(c8, hv, c9));
     const v2f u = __builtin_elementwise_fma(c10, hu, __builtin_elementwise_fma(c11, hv, c12));
-    const v2f rlo2 = {Q.r_lo, Q.r_lo};
-    const v2f w = r - rlo2;
     float m0 = __builtin_fminf(__builtin_fminf(s.x, t.x), u.x);
     float m1 = __builtin_fminf(__builtin_fminf(s.y, t.y), u.y);
     if (ROBUST) {
@@ -266,8 +264,35 @@ __device__ __forceinline__ void filter_z2(const v16f f, v2f px, v2f py, v2f pz, 
         m0 = __builtin_fmaf(gm, fabsf(rinv.x), m0);
         m1 = __builtin_fmaf(gm, fabsf(rinv.y), m1);
     }
-    *z0 = __builtin_fminf(m0, w.x);
-    *z1 = __builtin_fminf(m1, w.y);
+    *z0 = m0;
+    *z1 = m1;
+}
+
+// The ray-parameter term of the test for two rays: false only when r - r_lo < 0 for certain
+// (rare path; recomputes r exactly as filter_z2 does).
+template <int SHARED>
+__device__ __forceinline__ void filter_param2(const v16f f, v2f px, v2f py, v2f pz, v2f vx, v2f vy, v2f vz,
+                                              const FilterQuery Q, const float shared, bool* k0, bool* k1) {
+    const v2f n0 = {f[0], f[0]}, n1 = {f[1], f[1]}, n2 = {f[2], f[2]}, d0 = {f[3], f[3]};
+    v2f a, rinv;
+    if (SHARED == 2) {
+        rinv.x = rinv.y = shared;
+    } else {
+        v2f b = n0 * vx;
+        b = __builtin_elementwise_fma(n1, vy, b);
+        b = __builtin_elementwise_fma(n2, vz, b);
+        rinv.x = __builtin_amdgcn_rcpf(b.x); rinv.y = __builtin_amdgcn_rcpf(b.y);
+    }
+    if (SHARED == 1) {
+        a.x = a.y = shared;
+    } else {
+        a = __builtin_elementwise_fma(-n0, px, d0);
+        a = __builtin_elementwise_fma(-n1, py, a);
+        a = __builtin_elementwise_fma(-n2, pz, a);
+    }
+    const v2f r = a * rinv;
+    *k0 = !(r.x - Q.r_lo < 0.0f);
+    *k1 = !(r.y - Q.r_lo < 0.0f);
 }
 
 // The in-plane-origin term of the test for two rays (rare path; recomputes a and b).
@@ -374,24 +399,33 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
             for (int j = j0; j < jn; j++) {
                 const v16f nxt = filt[j + 1];
                 const float sh_nxt = SHARED ? shared[j + 1] : 0.0f;
-                float z[RPL], z_max = -INFINITY, a_min = INFINITY;
+                float z[RPL], a_min = INFINITY;
+                int z_top = INT_MIN;
 #pragma unroll
                 for (int q = 0; q < RPL / 2; q++) {
                     filter_z2<MODE, ROBUST, SHARED>(cur, L.px[q], L.py[q], L.pz[q], L.vx[q], L.vy[q], L.vz[q], pu[q], pv[q],
                                                     vu[q], vv[q], fp, sh_cur, &z[2 * q], &z[2 * q + 1], &a_min);
-                    z_max = __builtin_fmaxf(__builtin_fmaxf(z_max, z[2 * q]), z[2 * q + 1]);
+                    z_top = max(max(z_top, __float_as_int(z[2 * q])), __float_as_int(z[2 * q + 1]));
                 }
                 if (SHARED == 1) a_min = fabsf(sh_cur);
                 const bool maybe_in_plane = a_min <= fp.a_zero;
-                if ((z_max >= 0.0f) | maybe_in_plane) {               // rarely true for any lane of the wave
+                // "some z is >= 0 or NaN", asked of the bit patterns as signed integers: a float with
+                // a clear sign bit is a non-negative integer, a NaN with the sign bit set lies above
+                // the pattern of -inf (0xFF800000); every negative number (and -0) lies at or below it
+                if ((z_top > (int)0xFF800000) | maybe_in_plane) {      // rarely true for any lane of the wave
                     // (The empty asm statements pin this block's arithmetic inside the branch: the
                     // compiler would otherwise hoist it into the loop body that every triangle pays for.)
                     bool keep[RPL];
 #pragma unroll
-                    for (int r = 0; r < RPL; r++) {
-                        float zr = z[r];
-                        asm volatile("" : "+v"(zr));
-                        keep[r] = zr >= 0.0f;
+                    for (int q = 0; q < RPL / 2; q++) {
+                        float za = z[2 * q], zb = z[2 * q + 1];
+                        asm volatile("" : "+v"(za), "+v"(zb));
+                        bool k0, k1;
+                        v2f pxq = L.px[q], vxq = L.vx[q];
+                        asm volatile("" : "+v"(pxq), "+v"(vxq));
+                        filter_param2<SHARED>(cur, pxq, L.py[q], L.pz[q], vxq, L.vy[q], L.vz[q], fp, sh_cur, &k0, &k1);
+                        keep[2 * q] = !(za < 0.0f) & k0;
+                        keep[2 * q + 1] = !(zb < 0.0f) & k1;
                     }
                     if (maybe_in_plane) {
 #pragma unroll
