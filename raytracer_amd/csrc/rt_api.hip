@@ -168,6 +168,8 @@ struct rt_ctx {
     DevBuf<float> eye_a;                  // [n_regular + 1]
     DevBuf<float> dir_rinv;               // [directional lights][n_regular + 1]
     DevBuf<int32_t> light_dir_row;        // [n_lights]
+    DevBuf<float> cone_camera;            // [n_regular + 1][4]: bounding cone of each triangle seen from the eye
+    int pretest = 1;                      // bounding-volume tests in front of the FP32 triangle test
     std::vector<DevLight> h_lights;
     int shared_consts = 1;                // RT_OPT_SHARED_CONSTANTS
 
@@ -310,6 +312,7 @@ int launch_trace(rt_ctx* c, TraceArgs A, hipStream_t st, bool camera_rays = fals
     A.shared_origin_a = (MODE == 0 && camera_rays && c->shared_consts) ? c->eye_a.p : nullptr;
     A.shared_dir_rinv = (MODE == 1 && c->shared_consts && c->dir_rinv.n > 0) ? c->dir_rinv.p : nullptr;
     A.light_dir_row = c->light_dir_row.p;
+    A.cone_camera = (A.shared_origin_a && c->pretest && c->cone_camera.n > 0) ? c->cone_camera.p : nullptr;
     A.ray_flags = c->ray_flags[MODE].p; A.pairs = c->pairs[MODE].p; A.pair_count = c->pair_count[MODE].p;
     A.task_counter = (unsigned int*)(c->pair_count[MODE].p + 1);
     A.pair_cap = (unsigned int)c->pair_cap[MODE]; A.counters = c->counters.p; A.scan_all = c->force_exact;
@@ -325,12 +328,15 @@ int launch_trace(rt_ctx* c, TraceArgs A, hipStream_t st, bool camera_rays = fals
             ba.counters = (BvhCounters*)&c->counters.p->bvh_node_tests;
             hipLaunchKernelGGL(k_bvh_trace<MODE>, dim3(c->aux_grid), dim3(RT_BVH_BLOCK), 0, st, dsc, ba, A);
         } else {
-            if (c->robust)
-                hipLaunchKernelGGL((k_filter<MODE, RT_RPL, true>), dim3(c->filter_grid[MODE]), dim3(RT_BLOCK), 0, st, dsc,
-                                   (const v16f*)c->tri_filt.p, A);
-            else
-                hipLaunchKernelGGL((k_filter<MODE, RT_RPL, false>), dim3(c->filter_grid[MODE]), dim3(RT_BLOCK), 0, st, dsc,
-                                   (const v16f*)c->tri_filt.p, A);
+            const dim3 grid(c->filter_grid[MODE]), block(RT_BLOCK);
+            const v16f* records = (const v16f*)c->tri_filt.p;
+            if (MODE == 0 && A.cone_camera) {
+                if (c->robust) hipLaunchKernelGGL((k_filter<0, RT_RPL, true, 1>), grid, block, 0, st, dsc, records, A);
+                else hipLaunchKernelGGL((k_filter<0, RT_RPL, false, 1>), grid, block, 0, st, dsc, records, A);
+            } else {
+                if (c->robust) hipLaunchKernelGGL((k_filter<MODE, RT_RPL, true, 0>), grid, block, 0, st, dsc, records, A);
+                else hipLaunchKernelGGL((k_filter<MODE, RT_RPL, false, 0>), grid, block, 0, st, dsc, records, A);
+            }
         }
         HIP_TRY(hipGetLastError());
         t.stop();
@@ -512,6 +518,43 @@ int render_rows(rt_ctx* c, int y_start, int tile_rows, int stride_rows, int n_ti
 // Orders the triangles for the chosen form of the filter (regular ones by transform group and
 // dominant axis, then the irregular ones), builds the groups, and uploads the triangle records,
 // the groups and the scene header.  Called by rt_upload_scene and by RT_OPT_FILTER_FORM.
+// Smallest sphere around a triangle (centre in its plane): the circumscribed circle, or the
+// circle over the longest edge when the angle opposite to it is not acute.
+void bounding_sphere(const TriExact& ex, Vec* centre, double* radius) {
+    const Vec a{ex.v1[0], ex.v1[1], ex.v1[2]};
+    const Vec ab{ex.e2[0], ex.e2[1], ex.e2[2]}, ac{ex.e1[0], ex.e1[1], ex.e1[2]};   // v2 - v1, v3 - v1
+    const Vec bc = vsub(ac, ab);
+    const double lab = vdot(ab, ab), lac = vdot(ac, ac), lbc = vdot(bc, bc);
+    Vec rel;        // centre - a
+    if (lab >= lac + lbc) rel = {ab.x * .5, ab.y * .5, ab.z * .5};
+    else if (lac >= lab + lbc) rel = {ac.x * .5, ac.y * .5, ac.z * .5};
+    else if (lbc >= lab + lac) rel = {(ab.x + ac.x) * .5, (ab.y + ac.y) * .5, (ab.z + ac.z) * .5};
+    else {
+        const Vec n = vcross(ab, ac);
+        const double nn = vdot(n, n);
+        const Vec t1 = vcross(n, ab), t2 = vcross(ac, n);
+        rel = {(lac * t1.x + lab * t2.x) / (2 * nn), (lac * t1.y + lab * t2.y) / (2 * nn), (lac * t1.z + lab * t2.z) / (2 * nn)};
+    }
+    if (!(std::isfinite(rel.x) && std::isfinite(rel.y) && std::isfinite(rel.z))) rel = {(ab.x + ac.x) / 3, (ab.y + ac.y) / 3, (ab.z + ac.z) / 3};
+    *centre = {a.x + rel.x, a.y + rel.y, a.z + rel.z};
+    // the radius is measured, not derived: whatever the centre, the sphere holds the three vertices
+    const Vec da = rel, db = vsub(rel, ab), dc = vsub(rel, ac);
+    *radius = std::sqrt(std::max(vdot(da, da), std::max(vdot(db, db), vdot(dc, dc))));
+}
+
+// Cone from `apex` around the sphere (centre, radius): unit axis and cosine of the half-angle,
+// lowered by the rounding of the FP32 test; cos = -2 (every direction passes) when the apex is
+// inside the sphere or nearly so.
+void bounding_cone(Vec apex, Vec centre, double radius, float out[4]) {
+    const Vec d = vsub(centre, apex);
+    const double dist = vlen(d);
+    out[0] = 0.f; out[1] = 0.f; out[2] = 1.f; out[3] = -2.f;
+    if (!(dist > 0) || !std::isfinite(dist) || !(radius < 0.999 * dist)) return;
+    const double sn = radius / dist;
+    out[0] = (float)(d.x / dist); out[1] = (float)(d.y / dist); out[2] = (float)(d.z / dist);
+    out[3] = (float)(std::sqrt(1.0 - sn * sn) - 4e-6);
+}
+
 int install_filter(rt_ctx* c, int robust) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());          // no launch may still read the records replaced here
@@ -602,6 +645,9 @@ int install_filter(rt_ctx* c, int robust) {
     // (world-space direction against the untransformed normal, raytracer.cpp:553).
     {
         std::vector<float> eye_a((size_t)NR + 1, 0.f);
+        std::vector<float> cone_cam(4 * ((size_t)NR + 8), 0.f);      // readable a batch past the end
+        for (size_t k = (size_t)NR; k < (size_t)NR + 8; k++) cone_cam[4 * k + 3] = -2.f;
+        const double sphere_pad = 64.0 * 1.1920928955078125e-7 * c->scene_bound;
         const Vec eye{c->hs.cam_eye[0], c->hs.cam_eye[1], c->hs.cam_eye[2]};
         for (const Group& G : groups) {
             const Vec o = G.identity ? eye : affine_point(&c->h_xf[48 * (size_t)G.xf + 16], eye);
@@ -611,6 +657,11 @@ int install_filter(rt_ctx* c, int robust) {
                     const TriExact& ex = exact[k];
                     const Vec w0{o.x - ex.v1[0], o.y - ex.v1[1], o.z - ex.v1[2]};
                     eye_a[k] = (float)(-(ex.n[0] * w0.x + ex.n[1] * w0.y + ex.n[2] * w0.z));
+                    Vec centre; double radius;
+                    bounding_sphere(ex, &centre, &radius);
+                    bounding_cone(o, centre, (radius + ex.box_pad) * (1 + 1e-6) + sphere_pad, &cone_cam[4 * k]);
+                    // the in-plane-origin case (raytracer.cpp:319-325) ignores where the triangle is
+                    if (std::fabs(eye_a[k]) <= G.q[0].a_zero) cone_cam[4 * k + 3] = -2.f;
                 }
             });
         }
@@ -635,6 +686,7 @@ int install_filter(rt_ctx* c, int robust) {
             });
         }
         HIP_TRY(c->eye_a.upload(eye_a));
+        HIP_TRY(c->cone_camera.upload(cone_cam));
         HIP_TRY(c->light_dir_row.upload(row));
         if (n_rows > 0) HIP_TRY(c->dir_rinv.upload(rinv)); else c->dir_rinv.release();
     }
@@ -1030,8 +1082,8 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
     for (int m = 0; m < 2; m++) {
         int nb = 0;
         hipError_t oe = (m == 0)
-            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_filter<0, RT_RPL, true>, RT_BLOCK, 0)
-            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_filter<1, RT_RPL, true>, RT_BLOCK, 0);
+            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_filter<0, RT_RPL, true, 0>, RT_BLOCK, 0)
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_filter<1, RT_RPL, true, 0>, RT_BLOCK, 0);
         if (oe != hipSuccess || nb < 1) nb = 2;
         c->filter_grid[m] = c->n_cu * std::min(nb, 8);
     }
@@ -1199,7 +1251,7 @@ void rt_free(rt_ctx* c) {
     for (auto e : c->ev_phong) (void)hipEventDestroy(e);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     c->bvh_nodes.release(); c->bvh_groups.release(); c->bvh_spill.release();
-    c->eye_a.release(); c->dir_rinv.release(); c->light_dir_row.release();
+    c->eye_a.release(); c->dir_rinv.release(); c->light_dir_row.release(); c->cone_camera.release();
     delete c;
 }
 

@@ -124,6 +124,9 @@ struct TraceArgs {
     const float* shared_origin_a;        // MODE 0, camera rays only (all start at the eye): d0 - n.eye per slot; else null
     const float* shared_dir_rinv;        // MODE 1: [row][n_regular + 1] of 1 / (n.dir) for directional lights; may be null
     const int32_t* light_dir_row;        // MODE 1: per light, its row in shared_dir_rinv or -1 (point light)
+    // Bounding cones (see filter_range): per regular triangle (unit axis from the shared point to
+    // the centre of the triangle's bounding sphere, cosine of the half-angle).
+    const float* cone_camera;            // MODE 0, camera rays: [n_regular + 1][4]; else null
 };
 
 // Shadow rays are numbered light-major: ray = light * n_hits + hit, so that rays towards one
@@ -323,6 +326,7 @@ __device__ __forceinline__ void filter_in_plane2(const v16f f, v2f px, v2f py, v
 
 template <int RPL> struct FilterLane {     // ray slots 2q and 2q+1 share a float2
     v2f px[RPL / 2], py[RPL / 2], pz[RPL / 2], vx[RPL / 2], vy[RPL / 2], vz[RPL / 2];
+    v2f hx[RPL / 2], hy[RPL / 2], hz[RPL / 2];   // unit directions (only filled for tasks that use a cone test)
     unsigned int on;     // bit r: candidates of slot r count (the slot holds a ray the filter may judge)
 };
 
@@ -375,8 +379,20 @@ __device__ __forceinline__ void flush_candidates(const TraceArgs& A, const unsig
 // Filter loop over the regular triangles [abeg, aend) whose normals share the dominant axis AXIS.
 typedef __attribute__((address_space(4))) const float cfloat;
 
-template <int MODE, int RPL, int AXIS, bool ROBUST, int SHARED>
-__device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* shared, const TraceArgs& A,
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(4))) const v4f cv4f;
+typedef float v16u __attribute__((ext_vector_type(16), aligned(16)));      // four consecutive 16-byte records
+typedef __attribute__((address_space(4))) const v16u cv16u;
+
+// PRE = 1: before the triangle test proper, a test of the triangle's bounding sphere that costs
+// three multiply-adds per ray.  All rays of the task start at one point E; a hit the reference
+// can accept lies inside the sphere (its radius carries the same slack as the LBVH boxes), i.e.
+// inside the cone from E around the sphere, so a triangle none of the lane's unit directions
+// points into (h . axis < cos) cannot be hit by any of them and the whole lane skips it.  The
+// in-plane-origin case (raytracer.cpp:319-325) ignores where the triangle is: E in the plane is a
+// property of the triangle alone here (the shared constant a), checked on the scalar unit.
+template <int MODE, int RPL, int AXIS, bool ROBUST, int SHARED, int PRE>
+__device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* shared, const cv4f* cone, const TraceArgs& A,
                                              const FilterLane<RPL>& L, const FilterQuery fp, int abeg, int aend,
                                              unsigned short* my_cand, unsigned int ray0, unsigned int n_rays, int lane) {
     constexpr int SLOT_SHIFT = RT_SLOT_SHIFT(RPL);
@@ -387,67 +403,110 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
         pu[q] = pick_u<AXIS>(L.px[q], L.py[q], L.pz[q]); pv[q] = pick_v<AXIS>(L.px[q], L.py[q], L.pz[q]);
         vu[q] = pick_u<AXIS>(L.vx[q], L.vy[q], L.vz[q]); vv[q] = pick_v<AXIS>(L.vx[q], L.vy[q], L.vz[q]);
     }
-    for (int cbeg = abeg; cbeg < aend; cbeg += CHUNK) {
-        const int cend = min(cbeg + CHUNK, aend);
-        int n_cand = 0;
-        for (int j0 = cbeg; j0 < cend; j0 += RT_BATCH) {
-            const int jn = min(j0 + RT_BATCH, cend);
-            // The record of triangle j+1 is requested before triangle j is evaluated
-            // (the array carries one padding record, so j+1 is always readable).
-            v16f cur = filt[j0];
-            float sh_cur = SHARED ? shared[j0] : 0.0f;
-            for (int j = j0; j < jn; j++) {
-                const v16f nxt = filt[j + 1];
-                const float sh_nxt = SHARED ? shared[j + 1] : 0.0f;
-                float z[RPL], a_min = INFINITY;
-                int z_top = INT_MIN;
+    int n_cand = 0;
+    int cbeg = abeg;
+    // The FP32 test of triangle j (record `cur`, shared constant `sh_cur`) for the lanes that ask for it.
+    auto test_triangle = [&](const int j, const v16f cur, const float sh_cur) {
+        float z[RPL], a_min = INFINITY;
+        int z_top = INT_MIN;
+#pragma unroll
+        for (int q = 0; q < RPL / 2; q++) {
+            filter_z2<MODE, ROBUST, SHARED>(cur, L.px[q], L.py[q], L.pz[q], L.vx[q], L.vy[q], L.vz[q], pu[q], pv[q],
+                                            vu[q], vv[q], fp, sh_cur, &z[2 * q], &z[2 * q + 1], &a_min);
+            z_top = max(max(z_top, __float_as_int(z[2 * q])), __float_as_int(z[2 * q + 1]));
+        }
+        if (SHARED == 1) a_min = fabsf(sh_cur);
+        const bool maybe_in_plane = a_min <= fp.a_zero;
+        // "some z is >= 0 or NaN", asked of the bit patterns as signed integers: a float with
+        // a clear sign bit is a non-negative integer, a NaN with the sign bit set lies above
+        // the pattern of -inf (0xFF800000); every negative number (and -0) lies at or below it
+        if ((z_top > (int)0xFF800000) | maybe_in_plane) {      // rarely true for any lane of the wave
+            // (The empty asm statements pin this block's arithmetic inside the branch: the
+            // compiler would otherwise hoist it into the loop body that every triangle pays for.)
+            bool keep[RPL];
+#pragma unroll
+            for (int q = 0; q < RPL / 2; q++) {
+                float za = z[2 * q], zb = z[2 * q + 1];
+                asm volatile("" : "+v"(za), "+v"(zb));
+                bool k0, k1;
+                v2f pxq = L.px[q], vxq = L.vx[q];
+                asm volatile("" : "+v"(pxq), "+v"(vxq));
+                filter_param2<SHARED>(cur, pxq, L.py[q], L.pz[q], vxq, L.vy[q], L.vz[q], fp, sh_cur, &k0, &k1);
+                keep[2 * q] = !(za < 0.0f) & k0;
+                keep[2 * q + 1] = !(zb < 0.0f) & k1;
+            }
+            if (maybe_in_plane) {
 #pragma unroll
                 for (int q = 0; q < RPL / 2; q++) {
-                    filter_z2<MODE, ROBUST, SHARED>(cur, L.px[q], L.py[q], L.pz[q], L.vx[q], L.vy[q], L.vz[q], pu[q], pv[q],
-                                                    vu[q], vv[q], fp, sh_cur, &z[2 * q], &z[2 * q + 1], &a_min);
-                    z_top = max(max(z_top, __float_as_int(z[2 * q])), __float_as_int(z[2 * q + 1]));
+                    bool k0, k1;
+                    v2f pxq = L.px[q], vxq = L.vx[q];
+                    asm volatile("" : "+v"(pxq), "+v"(vxq));
+                    filter_in_plane2<ROBUST, SHARED>(cur, pxq, L.py[q], L.pz[q], vxq, L.vy[q], L.vz[q], fp, sh_cur, &k0, &k1);
+                    keep[2 * q] |= k0; keep[2 * q + 1] |= k1;
                 }
-                if (SHARED == 1) a_min = fabsf(sh_cur);
-                const bool maybe_in_plane = a_min <= fp.a_zero;
-                // "some z is >= 0 or NaN", asked of the bit patterns as signed integers: a float with
-                // a clear sign bit is a non-negative integer, a NaN with the sign bit set lies above
-                // the pattern of -inf (0xFF800000); every negative number (and -0) lies at or below it
-                if ((z_top > (int)0xFF800000) | maybe_in_plane) {      // rarely true for any lane of the wave
-                    // (The empty asm statements pin this block's arithmetic inside the branch: the
-                    // compiler would otherwise hoist it into the loop body that every triangle pays for.)
-                    bool keep[RPL];
+            }
 #pragma unroll
-                    for (int q = 0; q < RPL / 2; q++) {
-                        float za = z[2 * q], zb = z[2 * q + 1];
-                        asm volatile("" : "+v"(za), "+v"(zb));
-                        bool k0, k1;
-                        v2f pxq = L.px[q], vxq = L.vx[q];
-                        asm volatile("" : "+v"(pxq), "+v"(vxq));
-                        filter_param2<SHARED>(cur, pxq, L.py[q], L.pz[q], vxq, L.vy[q], L.vz[q], fp, sh_cur, &k0, &k1);
-                        keep[2 * q] = !(za < 0.0f) & k0;
-                        keep[2 * q + 1] = !(zb < 0.0f) & k1;
-                    }
-                    if (maybe_in_plane) {
+            for (int r = 0; r < RPL; r++) {
+                if (keep[r] && ((L.on >> r) & 1u)) {
+                    my_cand[n_cand * RT_BLOCK] = (unsigned short)((j - cbeg) | (r << SLOT_SHIFT));
+                    n_cand++;
+                }
+            }
+        }
+    };
+    v16f cones_cur = {}, cones_nxt = {};
+    for (cbeg = abeg; cbeg < aend; cbeg += CHUNK) {
+        const int cend = min(cbeg + CHUNK, aend);
+        n_cand = 0;
+        for (int j0 = cbeg; j0 < cend; j0 += RT_BATCH) {
+            const int jn = min(j0 + RT_BATCH, cend);
+            if (PRE) {
+                // The cone records of a batch (4 x 16 bytes) come in one scalar load, requested a
+                // batch ahead; the four tests run back to back (independent chains), one branch
+                // per batch asks whether any lane wants any of the four triangles, and only then
+                // is a triangle record fetched (the scalar cache cannot feed 64-byte records at
+                // the pace of the cone test).  The arrays are readable a batch past their end.
+                if (j0 == cbeg) cones_cur = *(const cv16u*)((const cfloat*)cone + 4 * (size_t)j0);
+                cones_nxt = *(const cv16u*)((const cfloat*)cone + 4 * (size_t)(j0 + RT_BATCH));
+                unsigned int want = 0;
 #pragma unroll
-                        for (int q = 0; q < RPL / 2; q++) {
-                            bool k0, k1;
-                            v2f pxq = L.px[q], vxq = L.vx[q];
-                            asm volatile("" : "+v"(pxq), "+v"(vxq));
-                            filter_in_plane2<ROBUST, SHARED>(cur, pxq, L.py[q], L.pz[q], vxq, L.vy[q], L.vz[q], fp, sh_cur,
-                                                             &k0, &k1);
-                            keep[2 * q] |= k0; keep[2 * q + 1] |= k1;
-                        }
-                    }
+                for (int jb = 0; jb < RT_BATCH; jb++) {
+                    const float ax = cones_cur[4 * jb], ay = cones_cur[4 * jb + 1], az = cones_cur[4 * jb + 2];
+                    const v2f cx = {ax, ax}, cy = {ay, ay}, cz = {az, az};
+                    v2f d[RPL / 2];
 #pragma unroll
-                    for (int r = 0; r < RPL; r++) {
-                        if (keep[r] && ((L.on >> r) & 1u)) {
-                            my_cand[n_cand * RT_BLOCK] = (unsigned short)((j - cbeg) | (r << SLOT_SHIFT));
-                            n_cand++;
-                        }
+                    for (int q = 0; q < RPL / 2; q++) d[q] = cx * L.hx[q];
+#pragma unroll
+                    for (int q = 0; q < RPL / 2; q++) d[q] = __builtin_elementwise_fma(cy, L.hy[q], d[q]);
+#pragma unroll
+                    for (int q = 0; q < RPL / 2; q++) d[q] = __builtin_elementwise_fma(cz, L.hz[q], d[q]);
+                    float top = __builtin_fmaxf(d[0].x, d[0].y);
+#pragma unroll
+                    for (int q = 1; q < RPL / 2; q++) top = __builtin_fmaxf(__builtin_fmaxf(top, d[q].x), d[q].y);
+                    // (cos = -2 where the shared origin may lie in the triangle's plane)
+                    if (top >= cones_cur[4 * jb + 3]) want |= 1u << jb;
+                }
+                if (want != 0) {                                  // rarely true for any lane of the wave
+#pragma unroll 1
+                    for (int jb = 0; jb < RT_BATCH; jb++) {
+                        const int j = j0 + jb;
+                        if (j >= jn) break;
+                        if ((want >> jb) & 1u) test_triangle(j, filt[j], SHARED ? shared[j] : 0.0f);
                     }
                 }
-                cur = nxt;
-                sh_cur = sh_nxt;
+                cones_cur = cones_nxt;
+            } else {
+                // The record of triangle j+1 is requested before triangle j is evaluated (the
+                // array carries padding records, so j+1 is always readable).
+                v16f cur = filt[j0];
+                float sh_cur = SHARED ? shared[j0] : 0.0f;
+                for (int j = j0; j < jn; j++) {
+                    const v16f nxt = filt[j + 1];
+                    const float sh_nxt = SHARED ? shared[j + 1] : 0.0f;
+                    test_triangle(j, cur, sh_cur);
+                    cur = nxt;
+                    sh_cur = sh_nxt;
+                }
             }
             // Flush when some lane could overflow its staging slots during the next batch,
             // and at the end of the chunk (entries are relative to the chunk base).
@@ -464,7 +523,7 @@ __device__ __forceinline__ float uniform_f(float x) {      // a value every lane
     return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
 }
 
-template <int MODE, int RPL, bool ROBUST>
+template <int MODE, int RPL, bool ROBUST, int CONE>
 __global__ void __launch_bounds__(RT_BLOCK, RT_FILTER_MIN_WAVES)
 k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, TraceArgs A) {
     // The filter records are never written while a kernel runs: reading them through the
@@ -509,10 +568,12 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
         const unsigned int ray0 = rb * RAYS_PER_TASK + lane;          // slot r: ray0 + r * 64
         // What the task's rays share (see filter_z2): camera rays their origin; shadow rays
         // towards one directional light their direction.
-        int shared_kind = 0;
+        int shared_kind = 0, cone_kind = 0;
         const cfloat* shared = nullptr;
+        const cv4f* cone = nullptr;
         if (MODE == 0) {
             if (A.shared_origin_a) { shared_kind = 1; shared = (const cfloat*)A.shared_origin_a; }
+            if (CONE == 1) { cone_kind = 1; cone = (const cv4f*)A.cone_camera; }
         } else if (A.shared_dir_rinv) {
             const unsigned int first = rb * RAYS_PER_TASK;
             const unsigned int last = min(first + RAYS_PER_TASK, n_rays) - 1u;
@@ -530,6 +591,7 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
         for (int k = 0; k < RPL / 2; k++) {
             const v2f zero = {0.f, 0.f}, one = {1.f, 1.f};
             L.px[k] = L.py[k] = L.pz[k] = L.vx[k] = L.vy[k] = zero; L.vz[k] = one;
+            L.hx[k] = L.hy[k] = zero; L.hz[k] = one;
         }
         for (int g = 0; g < n_groups; g++) {
             // group records are the same for every lane: keep the bounds in scalar registers
@@ -569,21 +631,37 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                     // full reference-precision scan of k_brute instead of the filter.
                     const bool trusted = fabsf(fx) <= ob && fabsf(fy) <= ob && fabsf(fz) <= ob &&
                                          (gx * gx + gy * gy + gz * gz) <= vb;
+                    float ux = 0.f, uy = 0.f, uz = 1.f;
+                    if (cone_kind) {
+                        const double inv_len = 1.0 / sqrt(vec.x * vec.x + vec.y * vec.y + vec.z * vec.z);
+                        ux = (float)(vec.x * inv_len); uy = (float)(vec.y * inv_len); uz = (float)(vec.z * inv_len);
+                    }
                     if (!trusted) {
                         if (valid && part == 0) A.ray_flags[ray] = 1;
-                        fx = 0.f; fy = 0.f; fz = 0.f; gx = 0.f; gy = 0.f; gz = 1.f;
+                        // (camera rays keep the origin they all share)
+                        if (CONE != 1) { fx = 0.f; fy = 0.f; fz = 0.f; }
+                        gx = 0.f; gy = 0.f; gz = 1.f;
                     }
                     if (valid && trusted) L.on |= 1u << r;
 #pragma unroll
                     for (int k = 0; k < RPL; k++) {
                         if (k == r) {
                             if (k & 1) { L.px[k / 2].y = fx; L.py[k / 2].y = fy; L.pz[k / 2].y = fz;
-                                         L.vx[k / 2].y = gx; L.vy[k / 2].y = gy; L.vz[k / 2].y = gz; }
+                                         L.vx[k / 2].y = gx; L.vy[k / 2].y = gy; L.vz[k / 2].y = gz;
+                                         L.hx[k / 2].y = ux; L.hy[k / 2].y = uy; L.hz[k / 2].y = uz; }
                             else { L.px[k / 2].x = fx; L.py[k / 2].x = fy; L.pz[k / 2].x = fz;
-                                   L.vx[k / 2].x = gx; L.vy[k / 2].x = gy; L.vz[k / 2].x = gz; }
+                                   L.vx[k / 2].x = gx; L.vy[k / 2].x = gy; L.vz[k / 2].x = gz;
+                                   L.hx[k / 2].x = ux; L.hy[k / 2].x = uy; L.hz[k / 2].x = uz; }
                         }
                     }
                 }
+            }
+            if (CONE == 1) {
+                // every slot of every lane holds the same origin (the eye in this group's space):
+                // say so, and the 24 registers become 3 scalar ones
+                const float ex = uniform_f(L.px[0].x), ey = uniform_f(L.py[0].x), ez = uniform_f(L.pz[0].x);
+#pragma unroll
+                for (int k = 0; k < RPL / 2; k++) { L.px[k] = {ex, ex}; L.py[k] = {ey, ey}; L.pz[k] = {ez, ez}; }
             }
             // each part takes its share of every axis range
 #pragma unroll
@@ -594,15 +672,21 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                 const int aend = min(fax[axis + 1], abeg + per_part);
                 if (abeg >= aend) continue;
                 constexpr int KIND = (MODE == 0) ? 1 : 2;
-                if (shared_kind == 0) {
-                    if (axis == 0) filter_range<MODE, RPL, 0, ROBUST, 0>(filt, shared, A, L, fp, abeg, aend, my_cand, ray0, n_rays, lane);
-                    if (axis == 1) filter_range<MODE, RPL, 1, ROBUST, 0>(filt, shared, A, L, fp, abeg, aend, my_cand, ray0, n_rays, lane);
-                    if (axis == 2) filter_range<MODE, RPL, 2, ROBUST, 0>(filt, shared, A, L, fp, abeg, aend, my_cand, ray0, n_rays, lane);
+#define RT_RANGE(AX, SH, PR) filter_range<MODE, RPL, AX, ROBUST, SH, PR>(filt, shared, cone, A, L, fp, abeg, aend, my_cand, ray0, n_rays, lane)
+                if (CONE == 1) {
+                    if (axis == 0) RT_RANGE(0, 1, 1);
+                    if (axis == 1) RT_RANGE(1, 1, 1);
+                    if (axis == 2) RT_RANGE(2, 1, 1);
+                } else if (shared_kind == 0) {
+                    if (axis == 0) RT_RANGE(0, 0, 0);
+                    if (axis == 1) RT_RANGE(1, 0, 0);
+                    if (axis == 2) RT_RANGE(2, 0, 0);
                 } else {
-                    if (axis == 0) filter_range<MODE, RPL, 0, ROBUST, KIND>(filt, shared, A, L, fp, abeg, aend, my_cand, ray0, n_rays, lane);
-                    if (axis == 1) filter_range<MODE, RPL, 1, ROBUST, KIND>(filt, shared, A, L, fp, abeg, aend, my_cand, ray0, n_rays, lane);
-                    if (axis == 2) filter_range<MODE, RPL, 2, ROBUST, KIND>(filt, shared, A, L, fp, abeg, aend, my_cand, ray0, n_rays, lane);
+                    if (axis == 0) RT_RANGE(0, KIND, 0);
+                    if (axis == 1) RT_RANGE(1, KIND, 0);
+                    if (axis == 2) RT_RANGE(2, KIND, 0);
                 }
+#undef RT_RANGE
             }
         }
     }
