@@ -168,7 +168,10 @@ struct rt_ctx {
     DevBuf<float> eye_a;                  // [n_regular + 1]
     DevBuf<float> dir_rinv;               // [directional lights][n_regular + 1]
     DevBuf<int32_t> light_dir_row;        // [n_lights]
-    DevBuf<float> cone_camera;            // [n_regular + 1][4]: bounding cone of each triangle seen from the eye
+    DevBuf<float> cone_camera;            // [n_regular + 8][4]: bounding cone of each triangle seen from the eye
+    DevBuf<float> bound_lights;           // [n_lights][n_regular + 8][4]: bounding cone / disc of each triangle per light
+    DevBuf<float> plane_dist_lights;      // [n_lights][n_regular + 8]: distance of a point light from each triangle's plane
+    DevBuf<double> light_frame;           // [n_lights][8]: plane coordinates of a directional light
     int pretest = 1;                      // bounding-volume tests in front of the FP32 triangle test
     std::vector<DevLight> h_lights;
     int shared_consts = 1;                // RT_OPT_SHARED_CONSTANTS
@@ -313,6 +316,10 @@ int launch_trace(rt_ctx* c, TraceArgs A, hipStream_t st, bool camera_rays = fals
     A.shared_dir_rinv = (MODE == 1 && c->shared_consts && c->dir_rinv.n > 0) ? c->dir_rinv.p : nullptr;
     A.light_dir_row = c->light_dir_row.p;
     A.cone_camera = (A.shared_origin_a && c->pretest && c->cone_camera.n > 0) ? c->cone_camera.p : nullptr;
+    const bool light_bounds = MODE == 1 && c->shared_consts && c->pretest && c->bound_lights.n > 0;
+    A.bound_lights = light_bounds ? c->bound_lights.p : nullptr;
+    A.plane_dist_lights = light_bounds ? c->plane_dist_lights.p : nullptr;
+    A.light_frame = light_bounds ? c->light_frame.p : nullptr;
     A.ray_flags = c->ray_flags[MODE].p; A.pairs = c->pairs[MODE].p; A.pair_count = c->pair_count[MODE].p;
     A.task_counter = (unsigned int*)(c->pair_count[MODE].p + 1);
     A.pair_cap = (unsigned int)c->pair_cap[MODE]; A.counters = c->counters.p; A.scan_all = c->force_exact;
@@ -333,6 +340,9 @@ int launch_trace(rt_ctx* c, TraceArgs A, hipStream_t st, bool camera_rays = fals
             if (MODE == 0 && A.cone_camera) {
                 if (c->robust) hipLaunchKernelGGL((k_filter<0, RT_RPL, true, 1>), grid, block, 0, st, dsc, records, A);
                 else hipLaunchKernelGGL((k_filter<0, RT_RPL, false, 1>), grid, block, 0, st, dsc, records, A);
+            } else if (MODE == 1 && A.bound_lights) {
+                if (c->robust) hipLaunchKernelGGL((k_filter<1, RT_RPL, true, 2>), grid, block, 0, st, dsc, records, A);
+                else hipLaunchKernelGGL((k_filter<1, RT_RPL, false, 2>), grid, block, 0, st, dsc, records, A);
             } else {
                 if (c->robust) hipLaunchKernelGGL((k_filter<MODE, RT_RPL, true, 0>), grid, block, 0, st, dsc, records, A);
                 else hipLaunchKernelGGL((k_filter<MODE, RT_RPL, false, 0>), grid, block, 0, st, dsc, records, A);
@@ -647,7 +657,18 @@ int install_filter(rt_ctx* c, int robust) {
         std::vector<float> eye_a((size_t)NR + 1, 0.f);
         std::vector<float> cone_cam(4 * ((size_t)NR + 8), 0.f);      // readable a batch past the end
         for (size_t k = (size_t)NR; k < (size_t)NR + 8; k++) cone_cam[4 * k + 3] = -2.f;
+        // bounding sphere of every regular triangle: what the reference can accept lies within
+        // box_pad of the triangle; the rest covers the rounding of centre and radius
+        std::vector<double> sphere(4 * (size_t)NR);
         const double sphere_pad = 64.0 * 1.1920928955078125e-7 * c->scene_bound;
+        parallel_ranges((size_t)NR, parts, [&](size_t, size_t k0, size_t k1) {
+            for (size_t k = k0; k < k1; k++) {
+                Vec centre; double radius;
+                bounding_sphere(exact[k], &centre, &radius);
+                sphere[4 * k] = centre.x; sphere[4 * k + 1] = centre.y; sphere[4 * k + 2] = centre.z;
+                sphere[4 * k + 3] = (radius + exact[k].box_pad) * (1 + 1e-6) + sphere_pad;
+            }
+        });
         const Vec eye{c->hs.cam_eye[0], c->hs.cam_eye[1], c->hs.cam_eye[2]};
         for (const Group& G : groups) {
             const Vec o = G.identity ? eye : affine_point(&c->h_xf[48 * (size_t)G.xf + 16], eye);
@@ -657,13 +678,76 @@ int install_filter(rt_ctx* c, int robust) {
                     const TriExact& ex = exact[k];
                     const Vec w0{o.x - ex.v1[0], o.y - ex.v1[1], o.z - ex.v1[2]};
                     eye_a[k] = (float)(-(ex.n[0] * w0.x + ex.n[1] * w0.y + ex.n[2] * w0.z));
-                    Vec centre; double radius;
-                    bounding_sphere(ex, &centre, &radius);
-                    bounding_cone(o, centre, (radius + ex.box_pad) * (1 + 1e-6) + sphere_pad, &cone_cam[4 * k]);
+                    bounding_cone(o, {sphere[4 * k], sphere[4 * k + 1], sphere[4 * k + 2]}, sphere[4 * k + 3], &cone_cam[4 * k]);
                     // the in-plane-origin case (raytracer.cpp:319-325) ignores where the triangle is
-                    if (std::fabs(eye_a[k]) <= G.q[0].a_zero) cone_cam[4 * k + 3] = -2.f;
+                    if (!(std::fabs(eye_a[k]) > G.q[0].a_zero)) cone_cam[4 * k + 3] = -2.f;
                 }
             });
+        }
+        // Per light (shadow rays meet the untransformed triangles in world space, raytracer.cpp:553):
+        // point light: cone from the light, and the light's distance from the triangle's plane;
+        // directional light: disc in the plane perpendicular to the light's direction, coordinates
+        // about the centre of the scene.
+        {
+            const size_t NL = c->h_lights.size(), stride = (size_t)NR + 8;
+            std::vector<float> bound(NL * stride * 4, 0.f), pdist(NL * stride, INFINITY);
+            std::vector<double> frame(std::max<size_t>(NL, 1) * 8, 0.0);
+            const double half = c->scene_bound;                       // bound of |origin| and |vertex| for every ray and triangle
+            const float shadow_b_hi = groups.empty() ? 0.f : groups[0].q[1].b_hi;
+            for (size_t l = 0; l < NL; l++) {
+                const DevLight& lt = c->h_lights[l];
+                float* B = &bound[l * stride * 4];
+                float* D = &pdist[l * stride];
+                for (size_t k = (size_t)NR; k < stride; k++) { B[4 * k + 2] = lt.is_point ? 1.f : -INFINITY; B[4 * k + 3] = lt.is_point ? 2.f : 0.f; }
+                if (lt.is_point) {
+                    const Vec Lp{lt.pos[0], lt.pos[1], lt.pos[2]};
+                    parallel_ranges((size_t)NR, parts, [&](size_t, size_t k0, size_t k1) {
+                        for (size_t k = k0; k < k1; k++) {
+                            const TriExact& ex = exact[k];
+                            bounding_cone(Lp, {sphere[4 * k], sphere[4 * k + 1], sphere[4 * k + 2]}, sphere[4 * k + 3], &B[4 * k]);
+                            const double a = ex.n[0] * (ex.v1[0] - Lp.x) + ex.n[1] * (ex.v1[1] - Lp.y) + ex.n[2] * (ex.v1[2] - Lp.z);
+                            D[k] = std::isfinite(a) ? (float)(std::fabs(a) * (1 - 1e-6)) : 0.f;
+                        }
+                    });
+                } else {
+                    // Light::lightRay: direction = (-pos).normalize() (raytracer.cpp:113-117)
+                    const double x = -lt.pos[0], y = -lt.pos[1], z = -lt.pos[2];
+                    const double len = std::sqrt(x * x + y * y + z * z), inv = 1. / len;
+                    const Vec dir{x * inv, y * inv, z * inv};
+                    // an orthonormal pair perpendicular to dir
+                    Vec t = std::fabs(dir.x) <= std::fabs(dir.y) && std::fabs(dir.x) <= std::fabs(dir.z) ? Vec{1, 0, 0}
+                          : (std::fabs(dir.y) <= std::fabs(dir.z) ? Vec{0, 1, 0} : Vec{0, 0, 1});
+                    Vec e1 = vcross(dir, t);
+                    const double l1 = vlen(e1);
+                    e1 = {e1.x / l1, e1.y / l1, e1.z / l1};
+                    const Vec e2 = vcross(dir, e1);
+                    const bool usable = std::isfinite(e1.x) && std::isfinite(e1.y) && std::isfinite(e1.z) && std::isfinite(e2.x) &&
+                                        std::isfinite(e2.y) && std::isfinite(e2.z);
+                    double* F = &frame[8 * l];
+                    F[0] = e1.x; F[1] = e1.y; F[2] = e1.z; F[3] = e2.x; F[4] = e2.y; F[5] = e2.z; F[6] = 0.0; F[7] = 0.0;
+                    // |coordinates| <= half; rounding of the expanded form, see filter_range
+                    const double rmax = half * (1 + 1e-3);
+                    const double slack = 16.0 * 1.1920928955078125e-7 * rmax * rmax;
+                    parallel_ranges((size_t)NR, parts, [&](size_t, size_t k0, size_t k1) {
+                        for (size_t k = k0; k < k1; k++) {
+                            const TriExact& ex = exact[k];
+                            const Vec ctr{sphere[4 * k], sphere[4 * k + 1], sphere[4 * k + 2]};
+                            const double cu = vdot(ctr, e1), cv = vdot(ctr, e2), rho = sphere[4 * k + 3];
+                            const double b = ex.n[0] * dir.x + ex.n[1] * dir.y + ex.n[2] * dir.z;
+                            double kk = rho * rho + 3.0 * 1.1920928955078125e-7 * rho * rmax - cu * cu - cv * cv + slack;
+                            // nearly parallel to the light (the in-plane-origin case can occur), or nothing usable
+                            if (!usable || !(std::fabs(b) > shadow_b_hi * (1 + 1e-3)) || !std::isfinite(kk)) kk = INFINITY;
+                            B[4 * k] = (float)(-2.0 * cu); B[4 * k + 1] = (float)(-2.0 * cv);
+                            B[4 * k + 2] = (kk == INFINITY) ? INFINITY : (float)kk + std::fabs((float)kk) * 1e-6f;
+                            B[4 * k + 3] = 0.f;
+                            if (!std::isfinite(B[4 * k]) || !std::isfinite(B[4 * k + 1])) { B[4 * k] = B[4 * k + 1] = 0.f; B[4 * k + 2] = INFINITY; }
+                        }
+                    });
+                }
+            }
+            HIP_TRY(c->bound_lights.upload(bound));
+            HIP_TRY(c->plane_dist_lights.upload(pdist));
+            HIP_TRY(c->light_frame.upload(frame));
         }
         std::vector<int32_t> row(std::max<size_t>(c->h_lights.size(), 1), -1);
         std::vector<float> rinv;
@@ -1252,6 +1336,7 @@ void rt_free(rt_ctx* c) {
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     c->bvh_nodes.release(); c->bvh_groups.release(); c->bvh_spill.release();
     c->eye_a.release(); c->dir_rinv.release(); c->light_dir_row.release(); c->cone_camera.release();
+    c->bound_lights.release(); c->plane_dist_lights.release(); c->light_frame.release();
     delete c;
 }
 

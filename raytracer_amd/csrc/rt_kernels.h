@@ -126,7 +126,12 @@ struct TraceArgs {
     const int32_t* light_dir_row;        // MODE 1: per light, its row in shared_dir_rinv or -1 (point light)
     // Bounding cones (see filter_range): per regular triangle (unit axis from the shared point to
     // the centre of the triangle's bounding sphere, cosine of the half-angle).
-    const float* cone_camera;            // MODE 0, camera rays: [n_regular + 1][4]; else null
+    const float* cone_camera;            // MODE 0, camera rays: [n_regular + 8][4]; else null
+    // MODE 1, per light l (row l of each array; null = no bounding tests):
+    const float* bound_lights;           // [n_lights][n_regular + 8][4]  point light: cone from the light (axis, cos);
+                                         //   directional light: (-2 cu, -2 cv, rho^2 - cu^2 - cv^2, 0) in the light's plane
+    const float* plane_dist_lights;      // [n_lights][n_regular + 8]     point light: distance of the light from the triangle's plane
+    const double* light_frame;           // [n_lights][8]  directional light: e1 (3), e2 (3), -O.e1, -O.e2
 };
 
 // Shadow rays are numbered light-major: ray = light * n_hits + hit, so that rays towards one
@@ -383,6 +388,8 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(4))) const v4f cv4f;
 typedef float v16u __attribute__((ext_vector_type(16), aligned(16)));      // four consecutive 16-byte records
 typedef __attribute__((address_space(4))) const v16u cv16u;
+typedef float v4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef __attribute__((address_space(4))) const v4u cv4u;
 
 // PRE = 1: before the triangle test proper, a test of the triangle's bounding sphere that costs
 // three multiply-adds per ray.  All rays of the task start at one point E; a hit the reference
@@ -391,8 +398,22 @@ typedef __attribute__((address_space(4))) const v16u cv16u;
 // points into (h . axis < cos) cannot be hit by any of them and the whole lane skips it.  The
 // in-plane-origin case (raytracer.cpp:319-325) ignores where the triangle is: E in the plane is a
 // property of the triangle alone here (the shared constant a), checked on the scalar unit.
+//
+// PRE = 2: shadow rays towards a point light.  Every ray lies on a line through the light, so
+// the same test works with the light as the apex and both nappes of the cone (the half-line
+// runs from the hit point through the light and on, raytracer.cpp:551-558): |v . axis| >= cos.
+// The in-plane-origin case needs the ray's origin in the triangle's plane and the ray nearly
+// parallel to it; then the light is within b_hi * (distance to the light) of that plane, which
+// is a property of the triangle and the task (`dist_thr`), checked on the scalar unit.
+//
+// PRE = 3: shadow rays towards a directional light are parallel: in the plane perpendicular
+// to the light's direction a ray is a point and the sphere a disc.  |p - c|^2 <= rho^2 is
+// evaluated as p.p - 2 p.c <= rho^2 - c.c (two multiply-adds per ray; the rounding of the
+// expanded form is part of the radius).  Triangles nearly parallel to the light's direction
+// (the in-plane-origin case) carry an infinite radius.
 template <int MODE, int RPL, int AXIS, bool ROBUST, int SHARED, int PRE>
-__device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* shared, const cv4f* cone, const TraceArgs& A,
+__device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* shared, const cv4f* cone,
+                                             const cfloat* plane_dist, const float dist_thr, const TraceArgs& A,
                                              const FilterLane<RPL>& L, const FilterQuery fp, int abeg, int aend,
                                              unsigned short* my_cand, unsigned int ray0, unsigned int n_rays, int lane) {
     constexpr int SLOT_SHIFT = RT_SLOT_SHIFT(RPL);
@@ -469,22 +490,46 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                 if (j0 == cbeg) cones_cur = *(const cv16u*)((const cfloat*)cone + 4 * (size_t)j0);
                 cones_nxt = *(const cv16u*)((const cfloat*)cone + 4 * (size_t)(j0 + RT_BATCH));
                 unsigned int want = 0;
+                v4f dists = {INFINITY, INFINITY, INFINITY, INFINITY};
+                if (PRE == 2) dists = *(const cv4u*)(plane_dist + j0);
 #pragma unroll
                 for (int jb = 0; jb < RT_BATCH; jb++) {
                     const float ax = cones_cur[4 * jb], ay = cones_cur[4 * jb + 1], az = cones_cur[4 * jb + 2];
                     const v2f cx = {ax, ax}, cy = {ay, ay}, cz = {az, az};
                     v2f d[RPL / 2];
+                    if (PRE == 3) {
 #pragma unroll
-                    for (int q = 0; q < RPL / 2; q++) d[q] = cx * L.hx[q];
+                        for (int q = 0; q < RPL / 2; q++) d[q] = __builtin_elementwise_fma(cy, L.hy[q], L.hz[q]);
 #pragma unroll
-                    for (int q = 0; q < RPL / 2; q++) d[q] = __builtin_elementwise_fma(cy, L.hy[q], d[q]);
+                        for (int q = 0; q < RPL / 2; q++) d[q] = __builtin_elementwise_fma(cx, L.hx[q], d[q]);
+                        float low = __builtin_fminf(d[0].x, d[0].y);
 #pragma unroll
-                    for (int q = 0; q < RPL / 2; q++) d[q] = __builtin_elementwise_fma(cz, L.hz[q], d[q]);
-                    float top = __builtin_fmaxf(d[0].x, d[0].y);
+                        for (int q = 1; q < RPL / 2; q++) low = __builtin_fminf(__builtin_fminf(low, d[q].x), d[q].y);
+                        if (low <= az) want |= 1u << jb;
+                    } else {
+                        const v2f* hx = (PRE == 2) ? L.vx : L.hx;         // shadow-ray directions have unit length
+                        const v2f* hy = (PRE == 2) ? L.vy : L.hy;
+                        const v2f* hz = (PRE == 2) ? L.vz : L.hz;
 #pragma unroll
-                    for (int q = 1; q < RPL / 2; q++) top = __builtin_fmaxf(__builtin_fmaxf(top, d[q].x), d[q].y);
-                    // (cos = -2 where the shared origin may lie in the triangle's plane)
-                    if (top >= cones_cur[4 * jb + 3]) want |= 1u << jb;
+                        for (int q = 0; q < RPL / 2; q++) d[q] = cx * hx[q];
+#pragma unroll
+                        for (int q = 0; q < RPL / 2; q++) d[q] = __builtin_elementwise_fma(cy, hy[q], d[q]);
+#pragma unroll
+                        for (int q = 0; q < RPL / 2; q++) d[q] = __builtin_elementwise_fma(cz, hz[q], d[q]);
+                        float top;
+                        if (PRE == 2) {
+                            top = __builtin_fmaxf(fabsf(d[0].x), fabsf(d[0].y));
+#pragma unroll
+                            for (int q = 1; q < RPL / 2; q++) top = __builtin_fmaxf(__builtin_fmaxf(top, fabsf(d[q].x)), fabsf(d[q].y));
+                        } else {
+                            top = __builtin_fmaxf(d[0].x, d[0].y);
+#pragma unroll
+                            for (int q = 1; q < RPL / 2; q++) top = __builtin_fmaxf(__builtin_fmaxf(top, d[q].x), d[q].y);
+                        }
+                        // (cos = -2 where the shared point may lie in the triangle's plane or inside the sphere)
+                        if (top >= cones_cur[4 * jb + 3]) want |= 1u << jb;
+                        if (PRE == 2 && !(fabsf(dists[jb]) > dist_thr)) want |= 1u << jb;
+                    }
                 }
                 if (want != 0) {                                  // rarely true for any lane of the wave
 #pragma unroll 1
@@ -542,7 +587,9 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
     // the queue length is the same for every lane: keep it (and all loop bounds derived from it) scalar
     const unsigned int n_hits = __builtin_amdgcn_readfirstlane(*A.n_items);
     const unsigned int n_rays = (MODE == 0) ? n_hits : n_hits * n_lights;
-    const unsigned int n_ray_blocks = (n_rays + RAYS_PER_TASK - 1) / RAYS_PER_TASK;
+    // Shadow rays are cut into blocks per light (a block never holds rays towards two lights).
+    const unsigned int blocks_per_light = (n_hits + RAYS_PER_TASK - 1) / RAYS_PER_TASK;
+    const unsigned int n_ray_blocks = (MODE == 0) ? blocks_per_light : blocks_per_light * n_lights;
     const int NR = sc->n_regular;
     if (NR == 0 || n_ray_blocks == 0) return;
     // Tasks = (block of 64*RPL rays) x (part of the triangle range), handed out through a
@@ -565,26 +612,35 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
         // integer division goes through the vector ALU; its result is still wave-uniform
         const int part = __builtin_amdgcn_readfirstlane((int)(task / n_ray_blocks));
         const unsigned int rb = task - (unsigned int)part * n_ray_blocks;
-        const unsigned int ray0 = rb * RAYS_PER_TASK + lane;          // slot r: ray0 + r * 64
-        // What the task's rays share (see filter_z2): camera rays their origin; shadow rays
-        // towards one directional light their direction.
-        int shared_kind = 0, cone_kind = 0;
+        // What the task's rays share (see filter_z2 and filter_range): camera rays their origin;
+        // shadow rays towards a directional light their direction, towards a point light the
+        // light's position.
+        unsigned int ray_base = rb * RAYS_PER_TASK, ray_end = n_rays;
+        int shared_kind = 0, cone_kind = 0, light = 0;
         const cfloat* shared = nullptr;
         const cv4f* cone = nullptr;
+        const cfloat* plane_dist = nullptr;
         if (MODE == 0) {
             if (A.shared_origin_a) { shared_kind = 1; shared = (const cfloat*)A.shared_origin_a; }
             if (CONE == 1) { cone_kind = 1; cone = (const cv4f*)A.cone_camera; }
-        } else if (A.shared_dir_rinv) {
-            const unsigned int first = rb * RAYS_PER_TASK;
-            const unsigned int last = min(first + RAYS_PER_TASK, n_rays) - 1u;
-            const int l0 = __builtin_amdgcn_readfirstlane((int)(first / n_hits));
-            const int l1 = __builtin_amdgcn_readfirstlane((int)(last / n_hits));
-            const int row = __builtin_amdgcn_readfirstlane(A.light_dir_row[l0]);
-            if (l0 == l1 && row >= 0) {
+        } else {
+            light = __builtin_amdgcn_readfirstlane((int)(rb / blocks_per_light));
+            const unsigned int b = rb - (unsigned int)light * blocks_per_light;
+            ray_base = (unsigned int)light * n_hits + b * RAYS_PER_TASK;
+            ray_end = ((unsigned int)light + 1u) * n_hits;
+            const int row = __builtin_amdgcn_readfirstlane(A.light_dir_row[light]);
+            if (A.shared_dir_rinv && row >= 0) {
                 shared_kind = 2;
                 shared = (const cfloat*)(A.shared_dir_rinv + (size_t)row * (size_t)(NR + 1));
             }
+            if (CONE == 2) {
+                cone_kind = (row >= 0) ? 3 : 2;
+                cone = (const cv4f*)(A.bound_lights + (size_t)light * (size_t)(NR + 8) * 4);
+                plane_dist = (const cfloat*)(A.plane_dist_lights + (size_t)light * (size_t)(NR + 8));
+            }
         }
+        const unsigned int ray0 = ray_base + lane;                    // slot r: ray0 + r * 64
+        float reach_max = 0.0f;                                       // CONE 2, point light: largest distance to the light
         bool have_rays = false;
         FilterLane<RPL> L;
 #pragma unroll
@@ -620,10 +676,10 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                     // A slot past the end of the queue mirrors the queue's last ray: its candidates are
                     // dropped (bit r of L.on stays clear), so no per-slot thresholds are needed.
                     const unsigned int ray = ray0 + r * RT_WAVE;
-                    const bool valid = ray < n_rays;
+                    const bool valid = ray < ray_end;
                     d3 pos, vec;
                     int source;
-                    load_world_ray<MODE>(A, sc, valid ? ray : n_rays - 1, n_hits, &pos, &vec, &source);
+                    load_world_ray<MODE>(A, sc, valid ? ray : ray_end - 1, n_hits, &pos, &vec, &source);
                     to_object_space(X, ident, &pos, &vec);
                     float fx = (float)pos.x, fy = (float)pos.y, fz = (float)pos.z;
                     float gx = (float)vec.x, gy = (float)vec.y, gz = (float)vec.z;
@@ -632,9 +688,22 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                     const bool trusted = fabsf(fx) <= ob && fabsf(fy) <= ob && fabsf(fz) <= ob &&
                                          (gx * gx + gy * gy + gz * gz) <= vb;
                     float ux = 0.f, uy = 0.f, uz = 1.f;
-                    if (cone_kind) {
+                    if (CONE == 1) {
                         const double inv_len = 1.0 / sqrt(vec.x * vec.x + vec.y * vec.y + vec.z * vec.z);
                         ux = (float)(vec.x * inv_len); uy = (float)(vec.y * inv_len); uz = (float)(vec.z * inv_len);
+                    }
+                    if (CONE == 2 && cone_kind == 3) {
+                        // the origin in the light's plane (coordinates about the scene's centre), and its square
+                        const double* F = A.light_frame + 8 * (size_t)light;
+                        ux = (float)(pos.x * F[0] + pos.y * F[1] + pos.z * F[2] + F[6]);
+                        uy = (float)(pos.x * F[3] + pos.y * F[4] + pos.z * F[5] + F[7]);
+                        uz = (float)((double)ux * (double)ux + (double)uy * (double)uy);
+                    }
+                    if (CONE == 2 && cone_kind == 2) {
+                        const DevLight& lt = sc->lights[light];
+                        const double lx = lt.pos[0] - pos.x, ly = lt.pos[1] - pos.y, lz = lt.pos[2] - pos.z;
+                        const float len = (float)(sqrt(lx * lx + ly * ly + lz * lz) * (1.0 + 1e-6));
+                        if (valid) reach_max = fmaxf(reach_max, len);          // (a NaN drops out; such a ray is flagged below)
                     }
                     if (!trusted) {
                         if (valid && part == 0) A.ray_flags[ray] = 1;
@@ -656,6 +725,12 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                     }
                 }
             }
+            float dist_thr = -1.0f;
+            if (CONE == 2 && cone_kind == 2) {
+                float m = reach_max;
+                for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+                dist_thr = uniform_f(m) * fp.b_hi + fp.a_zero;
+            }
             if (CONE == 1) {
                 // every slot of every lane holds the same origin (the eye in this group's space):
                 // say so, and the 24 registers become 3 scalar ones
@@ -672,11 +747,19 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                 const int aend = min(fax[axis + 1], abeg + per_part);
                 if (abeg >= aend) continue;
                 constexpr int KIND = (MODE == 0) ? 1 : 2;
-#define RT_RANGE(AX, SH, PR) filter_range<MODE, RPL, AX, ROBUST, SH, PR>(filt, shared, cone, A, L, fp, abeg, aend, my_cand, ray0, n_rays, lane)
+#define RT_RANGE(AX, SH, PR) filter_range<MODE, RPL, AX, ROBUST, SH, PR>(filt, shared, cone, plane_dist, dist_thr, A, L, fp, abeg, aend, my_cand, ray0, ray_end, lane)
                 if (CONE == 1) {
                     if (axis == 0) RT_RANGE(0, 1, 1);
                     if (axis == 1) RT_RANGE(1, 1, 1);
                     if (axis == 2) RT_RANGE(2, 1, 1);
+                } else if (CONE == 2 && cone_kind == 2) {
+                    if (axis == 0) RT_RANGE(0, 0, 2);
+                    if (axis == 1) RT_RANGE(1, 0, 2);
+                    if (axis == 2) RT_RANGE(2, 0, 2);
+                } else if (CONE == 2 && cone_kind == 3) {
+                    if (axis == 0) RT_RANGE(0, 2, 3);
+                    if (axis == 1) RT_RANGE(1, 2, 3);
+                    if (axis == 2) RT_RANGE(2, 2, 3);
                 } else if (shared_kind == 0) {
                     if (axis == 0) RT_RANGE(0, 0, 0);
                     if (axis == 1) RT_RANGE(1, 0, 0);
