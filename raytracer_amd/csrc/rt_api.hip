@@ -170,7 +170,6 @@ struct rt_ctx {
     DevBuf<int32_t> light_dir_row;        // [n_lights]
     DevBuf<float> cone_camera;            // [n_regular + 8][4]: bounding cone of each triangle seen from the eye
     DevBuf<float> bound_lights;           // [n_lights][n_regular + 8][4]: bounding cone / disc of each triangle per light
-    DevBuf<float> plane_dist_lights;      // [n_lights][n_regular + 8]: distance of a point light from each triangle's plane
     DevBuf<double> light_frame;           // [n_lights][8]: plane coordinates of a directional light
     int pretest = 1;                      // bounding-volume tests in front of the FP32 triangle test
     std::vector<DevLight> h_lights;
@@ -318,7 +317,6 @@ int launch_trace(rt_ctx* c, TraceArgs A, hipStream_t st, bool camera_rays = fals
     A.cone_camera = (A.shared_origin_a && c->pretest && c->cone_camera.n > 0) ? c->cone_camera.p : nullptr;
     const bool light_bounds = MODE == 1 && c->shared_consts && c->pretest && c->bound_lights.n > 0;
     A.bound_lights = light_bounds ? c->bound_lights.p : nullptr;
-    A.plane_dist_lights = light_bounds ? c->plane_dist_lights.p : nullptr;
     A.light_frame = light_bounds ? c->light_frame.p : nullptr;
     A.ray_flags = c->ray_flags[MODE].p; A.pairs = c->pairs[MODE].p; A.pair_count = c->pair_count[MODE].p;
     A.task_counter = (unsigned int*)(c->pair_count[MODE].p + 1);
@@ -690,23 +688,18 @@ int install_filter(rt_ctx* c, int robust) {
         // about the centre of the scene.
         {
             const size_t NL = c->h_lights.size(), stride = (size_t)NR + 8;
-            std::vector<float> bound(NL * stride * 4, 0.f), pdist(NL * stride, INFINITY);
+            std::vector<float> bound(NL * stride * 4, 0.f);
             std::vector<double> frame(std::max<size_t>(NL, 1) * 8, 0.0);
             const double half = c->scene_bound;                       // bound of |origin| and |vertex| for every ray and triangle
-            const float shadow_b_hi = groups.empty() ? 0.f : groups[0].q[1].b_hi;
             for (size_t l = 0; l < NL; l++) {
                 const DevLight& lt = c->h_lights[l];
                 float* B = &bound[l * stride * 4];
-                float* D = &pdist[l * stride];
                 for (size_t k = (size_t)NR; k < stride; k++) { B[4 * k + 2] = lt.is_point ? 1.f : -INFINITY; B[4 * k + 3] = lt.is_point ? 2.f : 0.f; }
                 if (lt.is_point) {
                     const Vec Lp{lt.pos[0], lt.pos[1], lt.pos[2]};
                     parallel_ranges((size_t)NR, parts, [&](size_t, size_t k0, size_t k1) {
                         for (size_t k = k0; k < k1; k++) {
-                            const TriExact& ex = exact[k];
                             bounding_cone(Lp, {sphere[4 * k], sphere[4 * k + 1], sphere[4 * k + 2]}, sphere[4 * k + 3], &B[4 * k]);
-                            const double a = ex.n[0] * (ex.v1[0] - Lp.x) + ex.n[1] * (ex.v1[1] - Lp.y) + ex.n[2] * (ex.v1[2] - Lp.z);
-                            D[k] = std::isfinite(a) ? (float)(std::fabs(a) * (1 - 1e-6)) : 0.f;
                         }
                     });
                 } else {
@@ -730,13 +723,10 @@ int install_filter(rt_ctx* c, int robust) {
                     const double slack = 16.0 * 1.1920928955078125e-7 * rmax * rmax;
                     parallel_ranges((size_t)NR, parts, [&](size_t, size_t k0, size_t k1) {
                         for (size_t k = k0; k < k1; k++) {
-                            const TriExact& ex = exact[k];
                             const Vec ctr{sphere[4 * k], sphere[4 * k + 1], sphere[4 * k + 2]};
                             const double cu = vdot(ctr, e1), cv = vdot(ctr, e2), rho = sphere[4 * k + 3];
-                            const double b = ex.n[0] * dir.x + ex.n[1] * dir.y + ex.n[2] * dir.z;
                             double kk = rho * rho + 3.0 * 1.1920928955078125e-7 * rho * rmax - cu * cu - cv * cv + slack;
-                            // nearly parallel to the light (the in-plane-origin case can occur), or nothing usable
-                            if (!usable || !(std::fabs(b) > shadow_b_hi * (1 + 1e-3)) || !std::isfinite(kk)) kk = INFINITY;
+                            if (!usable || !std::isfinite(kk)) kk = INFINITY;
                             B[4 * k] = (float)(-2.0 * cu); B[4 * k + 1] = (float)(-2.0 * cv);
                             B[4 * k + 2] = (kk == INFINITY) ? INFINITY : (float)kk + std::fabs((float)kk) * 1e-6f;
                             B[4 * k + 3] = 0.f;
@@ -746,7 +736,6 @@ int install_filter(rt_ctx* c, int robust) {
                 }
             }
             HIP_TRY(c->bound_lights.upload(bound));
-            HIP_TRY(c->plane_dist_lights.upload(pdist));
             HIP_TRY(c->light_frame.upload(frame));
         }
         std::vector<int32_t> row(std::max<size_t>(c->h_lights.size(), 1), -1);
@@ -1336,7 +1325,7 @@ void rt_free(rt_ctx* c) {
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     c->bvh_nodes.release(); c->bvh_groups.release(); c->bvh_spill.release();
     c->eye_a.release(); c->dir_rinv.release(); c->light_dir_row.release(); c->cone_camera.release();
-    c->bound_lights.release(); c->plane_dist_lights.release(); c->light_frame.release();
+    c->bound_lights.release(); c->light_frame.release();
     delete c;
 }
 

@@ -130,7 +130,6 @@ struct TraceArgs {
     // MODE 1, per light l (row l of each array; null = no bounding tests):
     const float* bound_lights;           // [n_lights][n_regular + 8][4]  point light: cone from the light (axis, cos);
                                          //   directional light: (-2 cu, -2 cv, rho^2 - cu^2 - cv^2, 0) in the light's plane
-    const float* plane_dist_lights;      // [n_lights][n_regular + 8]     point light: distance of the light from the triangle's plane
     const double* light_frame;           // [n_lights][8]  directional light: e1 (3), e2 (3), -O.e1, -O.e2
 };
 
@@ -402,18 +401,31 @@ typedef __attribute__((address_space(4))) const v4u cv4u;
 // PRE = 2: shadow rays towards a point light.  Every ray lies on a line through the light, so
 // the same test works with the light as the apex and both nappes of the cone (the half-line
 // runs from the hit point through the light and on, raytracer.cpp:551-558): |v . axis| >= cos.
-// The in-plane-origin case needs the ray's origin in the triangle's plane and the ray nearly
-// parallel to it; then the light is within b_hi * (distance to the light) of that plane, which
-// is a property of the triangle and the task (`dist_thr`), checked on the scalar unit.
 //
 // PRE = 3: shadow rays towards a directional light are parallel: in the plane perpendicular
 // to the light's direction a ray is a point and the sphere a disc.  |p - c|^2 <= rho^2 is
 // evaluated as p.p - 2 p.c <= rho^2 - c.c (two multiply-adds per ray; the rounding of the
-// expanded form is part of the radius).  Triangles nearly parallel to the light's direction
-// (the in-plane-origin case) carry an infinite radius.
+// expanded form is part of the radius).
+//
+// PRE = 2, 3 and the in-plane-origin case: it needs the ray's origin in the triangle's plane
+// and the ray nearly parallel to that plane.  Both have a necessary condition that involves
+// only the triangle's plane and what the task's rays share: the plane passes through the box
+// around the task's origins, and (point light: b * dist = (d0 - n.light) + a) the light lies
+// within b_hi * (largest distance to the light) of the plane, or (directional light) |n . dir|
+// <= b_hi.  Once per 64 triangles every lane evaluates that for one of them and a ballot turns
+// the answers into a scalar mask; triangles it names take the triangle test whatever the cone says.
+struct PlaneGuard {
+    const float* records;                // the filter records as plain memory (16 floats per triangle)
+    float lx, ly, lz;                    // point light: position; directional light: unit direction
+    float limit;                         // point light: b_hi * reach + 2 a_zero; directional light: b_hi (1 + 1e-3)
+    float cx, cy, cz, hx, hy, hz;        // box around the task's ray origins (centre, half extents)
+    float slack;                         // a_zero
+    int point;
+};
+
 template <int MODE, int RPL, int AXIS, bool ROBUST, int SHARED, int PRE>
 __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* shared, const cv4f* cone,
-                                             const cfloat* plane_dist, const float dist_thr, const TraceArgs& A,
+                                             const PlaneGuard& guard, const TraceArgs& A,
                                              const FilterLane<RPL>& L, const FilterQuery fp, int abeg, int aend,
                                              unsigned short* my_cand, unsigned int ray0, unsigned int n_rays, int lane) {
     constexpr int SLOT_SHIFT = RT_SLOT_SHIFT(RPL);
@@ -476,6 +488,8 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
         }
     };
     v16f cones_cur = {}, cones_nxt = {};
+    unsigned long long guard_mask = 0;
+    int guard_base = 0;
     for (cbeg = abeg; cbeg < aend; cbeg += CHUNK) {
         const int cend = min(cbeg + CHUNK, aend);
         n_cand = 0;
@@ -490,8 +504,21 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                 if (j0 == cbeg) cones_cur = *(const cv16u*)((const cfloat*)cone + 4 * (size_t)j0);
                 cones_nxt = *(const cv16u*)((const cfloat*)cone + 4 * (size_t)(j0 + RT_BATCH));
                 unsigned int want = 0;
-                v4f dists = {INFINITY, INFINITY, INFINITY, INFINITY};
-                if (PRE == 2) dists = *(const cv4u*)(plane_dist + j0);
+                if ((PRE == 2 || PRE == 3) && ((j0 - cbeg) & 63) == 0) {
+                    const int j = j0 + lane;
+                    bool named = false;
+                    if (j < cend) {
+                        const float4 pl = *(const float4*)(guard.records + 16 * (size_t)j);      // (n, d0)
+                        const float across = pl.x * guard.lx + pl.y * guard.ly + pl.z * guard.lz;
+                        const float off = guard.point ? fabsf(pl.w - across) : fabsf(across);
+                        const float centre = fabsf(pl.x * guard.cx + pl.y * guard.cy + pl.z * guard.cz - pl.w);
+                        const float reach = fabsf(pl.x) * guard.hx + fabsf(pl.y) * guard.hy + fabsf(pl.z) * guard.hz + guard.slack;
+                        named = !(off > guard.limit) && !(centre > reach);
+                    }
+                    guard_mask = __ballot(named);
+                    guard_base = j0;
+                }
+                if (PRE == 2 || PRE == 3) want = (unsigned int)(guard_mask >> (j0 - guard_base)) & ((1u << RT_BATCH) - 1u);
 #pragma unroll
                 for (int jb = 0; jb < RT_BATCH; jb++) {
                     const float ax = cones_cur[4 * jb], ay = cones_cur[4 * jb + 1], az = cones_cur[4 * jb + 2];
@@ -528,7 +555,6 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                         }
                         // (cos = -2 where the shared point may lie in the triangle's plane or inside the sphere)
                         if (top >= cones_cur[4 * jb + 3]) want |= 1u << jb;
-                        if (PRE == 2 && !(fabsf(dists[jb]) > dist_thr)) want |= 1u << jb;
                     }
                 }
                 if (want != 0) {                                  // rarely true for any lane of the wave
@@ -619,7 +645,6 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
         int shared_kind = 0, cone_kind = 0, light = 0;
         const cfloat* shared = nullptr;
         const cv4f* cone = nullptr;
-        const cfloat* plane_dist = nullptr;
         if (MODE == 0) {
             if (A.shared_origin_a) { shared_kind = 1; shared = (const cfloat*)A.shared_origin_a; }
             if (CONE == 1) { cone_kind = 1; cone = (const cv4f*)A.cone_camera; }
@@ -636,11 +661,12 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
             if (CONE == 2) {
                 cone_kind = (row >= 0) ? 3 : 2;
                 cone = (const cv4f*)(A.bound_lights + (size_t)light * (size_t)(NR + 8) * 4);
-                plane_dist = (const cfloat*)(A.plane_dist_lights + (size_t)light * (size_t)(NR + 8));
             }
         }
         const unsigned int ray0 = ray_base + lane;                    // slot r: ray0 + r * 64
         float reach_max = 0.0f;                                       // CONE 2, point light: largest distance to the light
+        float dir_x = 0.f, dir_y = 0.f, dir_z = 1.f;                  // CONE 2, directional light: the rays' direction
+        float box_lo[3] = {INFINITY, INFINITY, INFINITY}, box_hi[3] = {-INFINITY, -INFINITY, -INFINITY};   // CONE 2: the lane's origins
         bool have_rays = false;
         FilterLane<RPL> L;
 #pragma unroll
@@ -705,31 +731,68 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                         const float len = (float)(sqrt(lx * lx + ly * ly + lz * lz) * (1.0 + 1e-6));
                         if (valid) reach_max = fmaxf(reach_max, len);          // (a NaN drops out; such a ray is flagged below)
                     }
+                    if (CONE == 2 && valid && trusted) {
+                        box_lo[0] = fminf(box_lo[0], fx); box_lo[1] = fminf(box_lo[1], fy); box_lo[2] = fminf(box_lo[2], fz);
+                        box_hi[0] = fmaxf(box_hi[0], fx); box_hi[1] = fmaxf(box_hi[1], fy); box_hi[2] = fmaxf(box_hi[2], fz);
+                    }
                     if (!trusted) {
                         if (valid && part == 0) A.ray_flags[ray] = 1;
                         // (camera rays keep the origin they all share)
                         if (CONE != 1) { fx = 0.f; fy = 0.f; fz = 0.f; }
                         gx = 0.f; gy = 0.f; gz = 1.f;
                     }
+                    if (CONE == 2 && cone_kind == 3) {
+                        // Every ray of the task has the light's direction (kept in scalar registers);
+                        // the direction slots carry the origin in the light's plane instead.
+                        if (valid || r == 0) { dir_x = (float)vec.x; dir_y = (float)vec.y; dir_z = (float)vec.z; }
+                        gx = ux; gy = uy; gz = uz;
+                    }
                     if (valid && trusted) L.on |= 1u << r;
 #pragma unroll
                     for (int k = 0; k < RPL; k++) {
                         if (k == r) {
                             if (k & 1) { L.px[k / 2].y = fx; L.py[k / 2].y = fy; L.pz[k / 2].y = fz;
-                                         L.vx[k / 2].y = gx; L.vy[k / 2].y = gy; L.vz[k / 2].y = gz;
-                                         L.hx[k / 2].y = ux; L.hy[k / 2].y = uy; L.hz[k / 2].y = uz; }
+                                         L.vx[k / 2].y = gx; L.vy[k / 2].y = gy; L.vz[k / 2].y = gz; }
                             else { L.px[k / 2].x = fx; L.py[k / 2].x = fy; L.pz[k / 2].x = fz;
-                                   L.vx[k / 2].x = gx; L.vy[k / 2].x = gy; L.vz[k / 2].x = gz;
-                                   L.hx[k / 2].x = ux; L.hy[k / 2].x = uy; L.hz[k / 2].x = uz; }
+                                   L.vx[k / 2].x = gx; L.vy[k / 2].x = gy; L.vz[k / 2].x = gz; }
+                            if (CONE == 1) {
+                                if (k & 1) { L.hx[k / 2].y = ux; L.hy[k / 2].y = uy; L.hz[k / 2].y = uz; }
+                                else { L.hx[k / 2].x = ux; L.hy[k / 2].x = uy; L.hz[k / 2].x = uz; }
+                            }
                         }
                     }
                 }
             }
-            float dist_thr = -1.0f;
-            if (CONE == 2 && cone_kind == 2) {
+            PlaneGuard guard = {};
+            if (CONE == 2) {
                 float m = reach_max;
-                for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-                dist_thr = uniform_f(m) * fp.b_hi + fp.a_zero;
+                for (int off = 32; off > 0; off >>= 1) {
+                    m = fmaxf(m, __shfl_xor(m, off));
+#pragma unroll
+                    for (int a = 0; a < 3; a++) {
+                        box_lo[a] = fminf(box_lo[a], __shfl_xor(box_lo[a], off));
+                        box_hi[a] = fmaxf(box_hi[a], __shfl_xor(box_hi[a], off));
+                    }
+                }
+                const DevLight& lt = sc->lights[light];
+                guard.records = (const float*)filt_global;
+                guard.point = cone_kind == 2;
+                if (guard.point) {
+                    guard.lx = (float)lt.pos[0]; guard.ly = (float)lt.pos[1]; guard.lz = (float)lt.pos[2];
+                    // (the light may lie far outside the bounds a_zero was derived for: its own rounding on top)
+                    guard.limit = uniform_f(m) * fp.b_hi + 2.0f * fp.a_zero +
+                                  1e-6f * (fabsf(guard.lx) + fabsf(guard.ly) + fabsf(guard.lz));
+                } else {
+                    const double* F = A.light_frame + 8 * (size_t)light;       // e1 x e2 = the light's direction
+                    guard.lx = (float)(F[1] * F[5] - F[2] * F[4]); guard.ly = (float)(F[2] * F[3] - F[0] * F[5]);
+                    guard.lz = (float)(F[0] * F[4] - F[1] * F[3]);
+                    guard.limit = fp.b_hi * (1.0f + 1e-3f);
+                }
+                // (no trusted ray at all: lo = +inf, hi = -inf; the half extents become -inf and nothing is named)
+                guard.cx = uniform_f(0.5f * (box_lo[0] + box_hi[0])); guard.hx = uniform_f(0.5f * (box_hi[0] - box_lo[0]) * (1.0f + 1e-6f));
+                guard.cy = uniform_f(0.5f * (box_lo[1] + box_hi[1])); guard.hy = uniform_f(0.5f * (box_hi[1] - box_lo[1]) * (1.0f + 1e-6f));
+                guard.cz = uniform_f(0.5f * (box_lo[2] + box_hi[2])); guard.hz = uniform_f(0.5f * (box_hi[2] - box_lo[2]) * (1.0f + 1e-6f));
+                guard.slack = fp.a_zero;
             }
             if (CONE == 1) {
                 // every slot of every lane holds the same origin (the eye in this group's space):
@@ -747,7 +810,7 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                 const int aend = min(fax[axis + 1], abeg + per_part);
                 if (abeg >= aend) continue;
                 constexpr int KIND = (MODE == 0) ? 1 : 2;
-#define RT_RANGE(AX, SH, PR) filter_range<MODE, RPL, AX, ROBUST, SH, PR>(filt, shared, cone, plane_dist, dist_thr, A, L, fp, abeg, aend, my_cand, ray0, ray_end, lane)
+#define RT_RANGE(AX, SH, PR) filter_range<MODE, RPL, AX, ROBUST, SH, PR>(filt, shared, cone, guard, A, L, fp, abeg, aend, my_cand, ray0, ray_end, lane)
                 if (CONE == 1) {
                     if (axis == 0) RT_RANGE(0, 1, 1);
                     if (axis == 1) RT_RANGE(1, 1, 1);
@@ -757,9 +820,20 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                     if (axis == 1) RT_RANGE(1, 0, 2);
                     if (axis == 2) RT_RANGE(2, 0, 2);
                 } else if (CONE == 2 && cone_kind == 3) {
-                    if (axis == 0) RT_RANGE(0, 2, 3);
-                    if (axis == 1) RT_RANGE(1, 2, 3);
-                    if (axis == 2) RT_RANGE(2, 2, 3);
+                    const float sx = uniform_f(dir_x), sy = uniform_f(dir_y), sz = uniform_f(dir_z);
+                    FilterLane<RPL> D;
+                    D.on = L.on;
+#pragma unroll
+                    for (int k = 0; k < RPL / 2; k++) {
+                        D.px[k] = L.px[k]; D.py[k] = L.py[k]; D.pz[k] = L.pz[k];
+                        D.hx[k] = L.vx[k]; D.hy[k] = L.vy[k]; D.hz[k] = L.vz[k];
+                        D.vx[k] = {sx, sx}; D.vy[k] = {sy, sy}; D.vz[k] = {sz, sz};
+                    }
+#define RT_RANGE_D(AX) filter_range<MODE, RPL, AX, ROBUST, 2, 3>(filt, shared, cone, guard, A, D, fp, abeg, aend, my_cand, ray0, ray_end, lane)
+                    if (axis == 0) RT_RANGE_D(0);
+                    if (axis == 1) RT_RANGE_D(1);
+                    if (axis == 2) RT_RANGE_D(2);
+#undef RT_RANGE_D
                 } else if (shared_kind == 0) {
                     if (axis == 0) RT_RANGE(0, 0, 0);
                     if (axis == 1) RT_RANGE(1, 0, 0);
