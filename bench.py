@@ -7,11 +7,17 @@ every rank traces its interleaved 16-row scanline tiles through the C ABI
 (rt_render_tiles) and the tiles are gathered to rank 0.  Inputs (the uploaded scene) are
 resident in HBM before the timed region.  Rank 0 prints one JSON line.
 
-  roofline      the dominant kernel (the FP32 filter scan k_filter, nearest-hit or shadow
-                instance, whichever took longer):
+  roofline      the dominant kernel: the FP32 filter scan k_filter over rays that have nothing
+                in common (reflection rays), where every ray x triangle pair takes the FP32
+                triangle test:
                 algorithmic FLOP = ray x primitive pairs scanned x 42 (triangle) or 28
                 (sphere), divided by the kernel's summed duration measured with HIP events
                 on the launch stream, against the 157.3 TFLOP/s FP32 vector peak.
+                Launches whose rays pass through one point or are parallel (camera rays,
+                shadow rays) put a 2-3 multiply-add bounding test in front of the triangle
+                test; they are reported beside it as pairs per second ("bounded_scans"):
+                priced at 42 FLOP per pair they would exceed the peak, which is no statement
+                about the vector unit.
   cpu_baseline  the unmodified reference renderer (oracle/_ref, kind "reference") -- or the
                 C restatement when that binary is absent (kind "port") -- timed on this
                 box's host cores on sub-grids of the same frame (16 threads on every 4th pixel,
@@ -95,10 +101,11 @@ def measured_traffic(kernel_label, launches_per_frame):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.csv")))
     if not files:
         return None
-    want = "k_filter<0" if "<0>" in kernel_label else "k_filter<1"
     fetch = write = None
     for r in csv.DictReader(open(files[-1])):
-        if r["kernel"].startswith(want):
+        name = r["kernel"].replace(" ", "")
+        # (k_filter<MODE, rays per lane, form, bounding test>: the scan without a bounding test ends in 0>)
+        if name.startswith("k_filter<0,") and name.endswith(",0>"):
             if r["counter"] == "FETCH_SIZE":
                 fetch = float(r["sum_over_dispatches"])
             if r["counter"] == "WRITE_SIZE":
@@ -226,13 +233,25 @@ def main():
     if rank == 0:
         n_tri, n_sph = st["n_triangles"], st["n_spheres"]
         flop_per_test = (FLOP_TRI * n_tri + FLOP_SPH * n_sph) / max(1, n_tri + n_sph)
-        kernels = {"k_filter<0> (nearest hit)": (st["closest_ms"], st["closest_tests"], st["closest_launches"]),
-                   "k_filter<1> (shadow)": (st["anyhit_ms"], st["anyhit_tests"], st["anyhit_launches"])}
-        dom = max(kernels, key=lambda k: kernels[k][0])
-        ms, tests, launches = kernels[dom]
+        n_prim = n_tri + n_sph
+        cam_tests = st["rays_primary"] * n_prim if st["camera_launches"] else 0
+        cam_ms, cam_launches = st["camera_ms"], st["camera_launches"]
+        dom = "k_filter<0, 8, form, 0> (nearest hit, rays with nothing in common: every pair takes the FP32 triangle test)"
+        ms, tests, launches = st["closest_ms"] - cam_ms, st["closest_tests"] - cam_tests, st["closest_launches"] - cam_launches
+        if launches == 0:                  # depth 0: only camera rays; describe what there is
+            dom, ms, tests, launches = "k_filter<0> (camera rays)", cam_ms, cam_tests, cam_launches
         achieved = tests * flop_per_test / (ms * 1e-3) if ms > 0 else 0.0
         both_ms = st["closest_ms"] + st["anyhit_ms"]
         both = (st["closest_tests"] + st["anyhit_tests"]) * flop_per_test / (both_ms * 1e-3) if both_ms > 0 else 0.0
+
+        def scan(ms_sum, pairs, n_launches):
+            return {"ms_per_step": ms_sum / args.steps, "launches": n_launches,
+                    "pairs_per_s": pairs / (ms_sum * 1e-3) if ms_sum > 0 else 0.0,
+                    "at_42_flop_per_pair_tflops": pairs * flop_per_test / (ms_sum * 1e-3) / 1e12 if ms_sum > 0 else 0.0}
+        bounded = {"camera_rays": scan(cam_ms, cam_tests, cam_launches),
+                   "shadow_rays": scan(st["anyhit_ms"], st["anyhit_tests"], st["anyhit_launches"]),
+                   "note": "bounding-sphere test (2-3 multiply-adds per ray) in front of the triangle test; "
+                           "the 42-FLOP price of a pair is the triangle test's, so these figures are not roofline fractions"}
         n_cu, clock_khz = r.device_info()
         device_peak = (n_cu * 128 * 2 * clock_khz * 1e3) if clock_khz else None
         line = {
@@ -262,14 +281,15 @@ def main():
                                                          "clock_mhz": clock_khz / 1e3 if clock_khz else None,
                                                          "tflops": device_peak / 1e12 if device_peak else None},
                          # (the committed PMC pass is a 1-GPU run: its per-launch bytes describe N = 1 only)
-                         "traffic": measured_traffic(dom, launches / max(1, args.steps)) if world == 1 else None,
+                         "traffic": measured_traffic(dom, launches / max(1, args.steps)) if world == 1 and launches else None,
                          "kernel_ms_avg": ms / max(1, launches), "launches": launches,
                          "timing": "HIP events on the launch stream, K frames after the timed region with the "
                                    "library's two streams serialised (%.2f ms per frame that way)" % (serial_elapsed / args.steps * 1e3),
                          "rank0_whole_frame_tflops_in_timed_region": (st["closest_tests"] + st["anyhit_tests"]) * flop_per_test
                                                                      / args.steps / (elapsed / args.steps) / 1e12,
                          "flop_per_test": flop_per_test, "tests_per_launch": tests / max(1, launches),
-                         "both_filter_kernels_tflops": both / 1e12,
+                         "all_filter_launches_at_42_flop_per_pair_tflops": both / 1e12,
+                         "bounded_scans": bounded,
                          "filter_ms_per_step": both_ms / args.steps,
                          "reference_precision_kernels_ms_per_step": st["exact_ms"] / args.steps,
                          "exact_retests_per_ray": st["exact_tests"] / max(1, rays_local),

@@ -98,9 +98,15 @@ typedef enum rt_option {
     RT_OPT_SHARED_CONSTANTS = 6, /* 1 (default): the brute-force filter reads host-computed per-triangle constants
                                 where all rays of a launch share their origin (camera rays) or their direction
                                 (shadow rays towards a directional light); 0: every ray is treated alike */
-    RT_OPT_OVERLAP = 7       /* 1 (default): a level's shadow-ray launches run on an internal stream beside the
+    RT_OPT_OVERLAP = 7,      /* 1 (default): a level's shadow-ray launches run on an internal stream beside the
                                 next level's nearest-hit launches (joined back into the caller's stream before
                                 the call's last kernel); 0: one stream.  Off while RT_OPT_PROFILE is on */
+    RT_OPT_BOUNDING_TESTS = 8 /* 1 (default): where all rays of a launch pass through one point (camera rays: the
+                                eye; shadow rays: a point light) or are parallel (a directional light), the
+                                brute-force scan first asks whether any ray of a lane can reach the triangle's
+                                bounding sphere (2-3 multiply-adds per ray) and runs the triangle test only then;
+                                0: every pair takes the triangle test.  Needs RT_OPT_SHARED_CONSTANTS.  Frames
+                                are identical either way */
 } rt_option;
 
 /* Counters since rt_upload_scene or the last rt_reset_stats. */
@@ -123,6 +129,9 @@ typedef struct rt_stats {
     uint32_t closest_launches, anyhit_launches, exact_launches;
     int32_t n_triangles, n_spheres, n_groups, n_irregular;
     int32_t filter_form;     /* 1 = static margins, 2 = per-test margins (see RT_OPT_FILTER_FORM) */
+    double camera_ms;        /* RT_OPT_PROFILE: the part of closest_ms spent in launches of camera rays with
+                                RT_OPT_BOUNDING_TESTS on (the others scan rays that have nothing in common) */
+    uint32_t camera_launches, reserved;
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;

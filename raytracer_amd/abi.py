@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 RT_OK, RT_ERR_ARG, RT_ERR_DEVICE, RT_ERR_RANGE, RT_ERR_STATE = 0, -1, -2, -3, -4
 RT_OPT_EXACT_ONLY, RT_OPT_PROFILE, RT_OPT_PASS_PIXELS, RT_OPT_USE_BVH, RT_OPT_FILTER_FORM, RT_OPT_SHARED_CONSTANTS, RT_OPT_OVERLAP = 1, 2, 3, 4, 5, 6, 7
+RT_OPT_BOUNDING_TESTS = 8
 
 
 class RtMaterial(C.Structure):
@@ -54,6 +55,7 @@ class RtStats(C.Structure):
         ("closest_launches", C.c_uint32), ("anyhit_launches", C.c_uint32), ("exact_launches", C.c_uint32),
         ("n_triangles", C.c_int32), ("n_spheres", C.c_int32), ("n_groups", C.c_int32),
         ("n_irregular", C.c_int32), ("filter_form", C.c_int32),
+        ("camera_ms", C.c_double), ("camera_launches", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
     def as_dict(self):

@@ -197,8 +197,8 @@ struct rt_ctx {
     struct Span { hipEvent_t a, b; int kind; };
     std::vector<Span> spans;
     std::vector<hipEvent_t> event_pool;
-    double ms[3] = {0, 0, 0};      // filter MODE 0, filter MODE 1, reference-precision kernels
-    unsigned launches[3] = {0, 0, 0};
+    double ms[4] = {0, 0, 0, 0};   // filter MODE 0 (rays with nothing in common), filter MODE 1, reference-precision kernels, filter MODE 0 of camera rays
+    unsigned launches[4] = {0, 0, 0, 0};
 };
 
 namespace {
@@ -324,7 +324,7 @@ int launch_trace(rt_ctx* c, TraceArgs A, hipStream_t st, bool camera_rays = fals
     HIP_TRY(hipMemsetAsync(c->pair_count[MODE].p, 0, 2 * sizeof(unsigned long long), st));
     HIP_TRY(hipMemsetAsync(c->ray_flags[MODE].p, 0, c->ray_flags[MODE].n, st));
     if (!c->force_exact && c->hs.n_regular > 0) {
-        Timed t(c, st, MODE);
+        Timed t(c, st, (MODE == 0 && A.cone_camera && !c->use_bvh) ? 3 : MODE);
         if (c->use_bvh) {
             BvhArgs ba;
             ba.bvh = c->bvh_groups.p; ba.nodes = c->bvh_nodes.p; ba.filt = (const float*)c->tri_filt.p;
@@ -1186,6 +1186,7 @@ int rt_set_option(rt_ctx* c, int option, int64_t value) {
         }
         case RT_OPT_SHARED_CONSTANTS: c->shared_consts = value ? 1 : 0; return 0;
         case RT_OPT_OVERLAP: c->overlap = value ? 1 : 0; return 0;
+        case RT_OPT_BOUNDING_TESTS: c->pretest = value ? 1 : 0; return 0;
         case RT_OPT_USE_BVH:
             if (value) {
                 int rc = build_bvh(c);
@@ -1278,8 +1279,9 @@ int rt_get_stats(rt_ctx* c, rt_stats* out) {
     out->exact_tests = dc.exact_tests;
     out->bvh_node_tests = dc.bvh_node_tests; out->bvh_leaf_tests = dc.bvh_leaf_tests;
     out->in_plane_origin_hits = dc.in_plane_origin_hits; out->flagged_rays = dc.flagged_rays;
-    out->closest_ms = c->ms[0]; out->anyhit_ms = c->ms[1];
-    out->closest_launches = c->launches[0]; out->anyhit_launches = c->launches[1];
+    out->closest_ms = c->ms[0] + c->ms[3]; out->anyhit_ms = c->ms[1];
+    out->closest_launches = c->launches[0] + c->launches[3]; out->anyhit_launches = c->launches[1];
+    out->camera_ms = c->ms[3]; out->camera_launches = c->launches[3]; out->reserved = 0;
     out->exact_ms = c->ms[2]; out->exact_launches = c->launches[2];
     out->n_triangles = c->hs.n_regular + c->hs.n_irregular; out->n_spheres = c->hs.n_spheres;
     out->n_groups = c->hs.n_groups; out->n_irregular = c->hs.n_irregular;
@@ -1292,7 +1294,7 @@ int rt_reset_stats(rt_ctx* c) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->last_stream));
     drain_spans(c);
-    for (int k = 0; k < 3; k++) { c->ms[k] = 0; c->launches[k] = 0; }
+    for (int k = 0; k < 4; k++) { c->ms[k] = 0; c->launches[k] = 0; }
     HIP_TRY(hipMemset(c->counters.p, 0, sizeof(DevCounters)));
     return 0;
 }

@@ -153,12 +153,13 @@ def test_every_configuration_equals_exact_only(family, seed, tmp_path):
     want, sw = render(sc, EXACT_ONLY=1)
     in_plane = None
     for form in (1, 2):
-        for shared in (1, 0):
-            img, st = render(sc, FILTER_FORM=form, SHARED_CONSTANTS=shared)
-            assert np.array_equal(img, want), (form, shared, int((img != want).any(axis=-1).sum()))
+        # shared constants with and without the bounding tests in front of the triangle test, then neither
+        for more in ({"SHARED_CONSTANTS": 1}, {"SHARED_CONSTANTS": 1, "BOUNDING_TESTS": 0}, {"SHARED_CONSTANTS": 0}):
+            img, st = render(sc, FILTER_FORM=form, **more)
+            assert np.array_equal(img, want), (form, more, int((img != want).any(axis=-1).sum()))
             for key in ("rays_reflect", "rays_shadow", "hits"):
-                assert st[key] == sw[key], (key, form, shared)
-            in_plane = st["in_plane_origin_hits"]
+                assert st[key] == sw[key], (key, form, more)
+            in_plane = st["in_plane_origin_hits"] if in_plane is None else max(in_plane, st["in_plane_origin_hits"])
         # The LBVH cannot see the reference's in-plane-origin "hits" (a box test has no notion of
         # an infinite plane); the brute-force counter says whether this scene has any.
         if in_plane == 0:

@@ -30,11 +30,14 @@ def scene_file(name):
     raise FileNotFoundError(name)
 
 
-def gpu_render(sc, exact_only=False, pass_pixels=None, tiles=None, filter_form=None, bvh=False, shared=None):
+def gpu_render(sc, exact_only=False, pass_pixels=None, tiles=None, filter_form=None, bvh=False, shared=None,
+               bounding=None):
     from raytracer_amd.render import Renderer
     r = Renderer(sc)
     if shared is not None:
         r.set_option(abi.RT_OPT_SHARED_CONSTANTS, shared)
+    if bounding is not None:
+        r.set_option(abi.RT_OPT_BOUNDING_TESTS, bounding)
     if filter_form is not None:
         r.set_option(abi.RT_OPT_FILTER_FORM, filter_form)
     if bvh:
@@ -107,6 +110,26 @@ def test_shared_origin_and_direction_constants_change_nothing(name, w, h, depth)
         assert np.array_equal(a, b), form
         for k in ("rays_primary", "rays_reflect", "rays_shadow", "hits"):
             assert sa[k] == sb[k], (k, form)
+
+
+@pytest.mark.parametrize("name,w,h,depth", [("teapot", 1280, 720, 5), ("mixed_xf", 640, 480, 6), ("input-06", 512, 384, 6),
+                                           ("campanile_teddy", 480, 270, 3), ("synthetic_small", 480, 270, 4),
+                                           ("normals", 320, 240, 4), ("journal2", 320, 240, 6)])
+def test_bounding_tests_change_nothing(name, w, h, depth):
+    """Where the rays of a launch pass through one point (camera rays, shadow rays towards a point
+    light) or are parallel (a directional light) the scan asks a bounding-sphere question before
+    the triangle test.  Same frame and counts with and without, in both forms of the filter; the
+    triangle test itself must see no more pairs than without (the question can only remove some)."""
+    sc = Scene.load(scene_file(name), w, h, depth)
+    for form in (1, 2):
+        a, sa = gpu_render(sc, filter_form=form, bounding=1)
+        b, sb = gpu_render(sc, filter_form=form, bounding=0)
+        assert np.array_equal(a, b), form
+        for k in ("rays_primary", "rays_reflect", "rays_shadow", "hits", "closest_tests", "anyhit_tests", "in_plane_origin_hits"):
+            assert sa[k] == sb[k], (k, form)
+        assert sa["exact_tests"] <= sb["exact_tests"]
+    c, _ = gpu_render(sc, exact_only=True)
+    assert np.array_equal(a, c)
 
 
 @pytest.mark.parametrize("name,w,h,depth,bvh", [("teapot", 320, 180, 5, False), ("mixed_xf", 320, 240, 6, False),
