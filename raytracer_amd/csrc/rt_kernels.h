@@ -630,10 +630,20 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
     const unsigned int n_tasks = n_ray_blocks * (unsigned int)split;
     const int n_groups = sc->n_groups;
 
+    // A wave's first task is its own number; further ones come from the counter.  A launch with
+    // fewer tasks than waves (the deep reflection levels) then costs the idle waves nothing: a
+    // few thousand waves queueing at one counter only to learn that there is no work set a
+    // floor of ~0.1 ms under every launch.
+    const unsigned int wave_id = blockIdx.x * (RT_BLOCK / RT_WAVE) + (unsigned int)wave_in_block;
+    bool first_task = true;
     for (;;) {
-        unsigned int task = 0;
-        if (lane == 0) task = atomicAdd(A.task_counter, 1u);
-        task = __builtin_amdgcn_readfirstlane(task);
+        unsigned int task = wave_id;
+        if (!first_task) {
+            unsigned int t = 0;
+            if (lane == 0) t = atomicAdd(A.task_counter, 1u);
+            task = n_waves + (unsigned int)__builtin_amdgcn_readfirstlane(t);
+        }
+        first_task = false;
         if (task >= n_tasks) break;
         // integer division goes through the vector ALU; its result is still wave-uniform
         const int part = __builtin_amdgcn_readfirstlane((int)(task / n_ray_blocks));
