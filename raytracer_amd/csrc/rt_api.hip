@@ -171,6 +171,8 @@ struct rt_ctx {
     DevBuf<float> cone_camera;            // [n_regular + 8][4]: bounding cone of each triangle seen from the eye
     DevBuf<float> bound_lights;           // [n_lights][n_regular + 8][4]: bounding cone / disc of each triangle per light
     DevBuf<double> light_frame;           // [n_lights][8]: plane coordinates of a directional light
+    DevBuf<float> sphere_any, plane_any;  // [n_regular + 8][4] each: bounding sphere / plane of each triangle (rays with nothing in common)
+    int pretest_any = 1;                  // ... and whether those are used
     int pretest = 1;                      // bounding-volume tests in front of the FP32 triangle test
     std::vector<DevLight> h_lights;
     int shared_consts = 1;                // RT_OPT_SHARED_CONSTANTS
@@ -315,6 +317,9 @@ int launch_trace(rt_ctx* c, TraceArgs A, hipStream_t st, bool camera_rays = fals
     A.shared_dir_rinv = (MODE == 1 && c->shared_consts && c->dir_rinv.n > 0) ? c->dir_rinv.p : nullptr;
     A.light_dir_row = c->light_dir_row.p;
     A.cone_camera = (A.shared_origin_a && c->pretest && c->cone_camera.n > 0) ? c->cone_camera.p : nullptr;
+    const bool any_bounds = MODE == 0 && !camera_rays && c->pretest && c->pretest_any && c->sphere_any.n > 0;
+    A.sphere_any = any_bounds ? c->sphere_any.p : nullptr;
+    A.plane_any = any_bounds ? c->plane_any.p : nullptr;
     const bool light_bounds = MODE == 1 && c->shared_consts && c->pretest && c->bound_lights.n > 0;
     A.bound_lights = light_bounds ? c->bound_lights.p : nullptr;
     A.light_frame = light_bounds ? c->light_frame.p : nullptr;
@@ -338,6 +343,9 @@ int launch_trace(rt_ctx* c, TraceArgs A, hipStream_t st, bool camera_rays = fals
             if (MODE == 0 && A.cone_camera) {
                 if (c->robust) hipLaunchKernelGGL((k_filter<0, RT_RPL, true, 1>), grid, block, 0, st, dsc, records, A);
                 else hipLaunchKernelGGL((k_filter<0, RT_RPL, false, 1>), grid, block, 0, st, dsc, records, A);
+            } else if (MODE == 0 && A.sphere_any) {
+                if (c->robust) hipLaunchKernelGGL((k_filter<0, RT_RPL, true, 4>), grid, block, 0, st, dsc, records, A);
+                else hipLaunchKernelGGL((k_filter<0, RT_RPL, false, 4>), grid, block, 0, st, dsc, records, A);
             } else if (MODE == 1 && A.bound_lights) {
                 if (c->robust) hipLaunchKernelGGL((k_filter<1, RT_RPL, true, 2>), grid, block, 0, st, dsc, records, A);
                 else hipLaunchKernelGGL((k_filter<1, RT_RPL, false, 2>), grid, block, 0, st, dsc, records, A);
@@ -667,13 +675,31 @@ int install_filter(rt_ctx* c, int robust) {
                 sphere[4 * k + 3] = (radius + exact[k].box_pad) * (1 + 1e-6) + sphere_pad;
             }
         });
+        // rays with nothing in common: sphere as (centre, rho^2 - |centre|^2 + rounding of the expanded
+        // distance test, 64 eps R^2 with R the group's bound on |origin| and |vertex|), plane as (n, d0)
+        std::vector<float> sphere_any(4 * ((size_t)NR + 8), 0.f), plane_any(4 * ((size_t)NR + 8), 0.f);
+        for (size_t k = (size_t)NR; k < (size_t)NR + 8; k++) { sphere_any[4 * k + 3] = -INFINITY; plane_any[4 * k + 3] = INFINITY; }
         const Vec eye{c->hs.cam_eye[0], c->hs.cam_eye[1], c->hs.cam_eye[2]};
         for (const Group& G : groups) {
             const Vec o = G.identity ? eye : affine_point(&c->h_xf[48 * (size_t)G.xf + 16], eye);
             const size_t first = (size_t)G.fax[0], count = (size_t)(G.fax[3] - G.fax[0]);
+            const double Rg = (double)G.q[0].e_a / (16.0 * 1.1920928955078125e-7) * (1 + 1e-3);
+            const double slack_any = 64.0 * 1.1920928955078125e-7 * Rg * Rg;
             parallel_ranges(count, host_parts(count), [&](size_t, size_t k0, size_t k1) {
                 for (size_t k = first + k0; k < first + k1; k++) {
                     const TriExact& ex = exact[k];
+                    {
+                        const double cx = sphere[4 * k], cy = sphere[4 * k + 1], cz = sphere[4 * k + 2], rho = sphere[4 * k + 3];
+                        const double kk = rho * rho - (cx * cx + cy * cy + cz * cz) + slack_any;
+                        sphere_any[4 * k] = (float)cx; sphere_any[4 * k + 1] = (float)cy; sphere_any[4 * k + 2] = (float)cz;
+                        float kf = std::isfinite(kk) ? (float)kk : INFINITY;
+                        if (std::isfinite(kf)) kf += std::fabs(kf) * 1e-6f;
+                        if (!std::isfinite(sphere_any[4 * k]) || !std::isfinite(sphere_any[4 * k + 1]) || !std::isfinite(sphere_any[4 * k + 2])) {
+                            sphere_any[4 * k] = sphere_any[4 * k + 1] = sphere_any[4 * k + 2] = 0.f; kf = INFINITY;
+                        }
+                        sphere_any[4 * k + 3] = kf;
+                        for (int q = 0; q < 4; q++) plane_any[4 * k + q] = filt[k][q];
+                    }
                     const Vec w0{o.x - ex.v1[0], o.y - ex.v1[1], o.z - ex.v1[2]};
                     eye_a[k] = (float)(-(ex.n[0] * w0.x + ex.n[1] * w0.y + ex.n[2] * w0.z));
                     bounding_cone(o, {sphere[4 * k], sphere[4 * k + 1], sphere[4 * k + 2]}, sphere[4 * k + 3], &cone_cam[4 * k]);
@@ -760,6 +786,7 @@ int install_filter(rt_ctx* c, int robust) {
         }
         HIP_TRY(c->eye_a.upload(eye_a));
         HIP_TRY(c->cone_camera.upload(cone_cam));
+        HIP_TRY(c->sphere_any.upload(sphere_any)); HIP_TRY(c->plane_any.upload(plane_any));
         HIP_TRY(c->light_dir_row.upload(row));
         if (n_rows > 0) HIP_TRY(c->dir_rinv.upload(rinv)); else c->dir_rinv.release();
     }
@@ -1186,7 +1213,7 @@ int rt_set_option(rt_ctx* c, int option, int64_t value) {
         }
         case RT_OPT_SHARED_CONSTANTS: c->shared_consts = value ? 1 : 0; return 0;
         case RT_OPT_OVERLAP: c->overlap = value ? 1 : 0; return 0;
-        case RT_OPT_BOUNDING_TESTS: c->pretest = value ? 1 : 0; return 0;
+        case RT_OPT_BOUNDING_TESTS: c->pretest = value ? 1 : 0; c->pretest_any = value == 1 ? 1 : 0; return 0;
         case RT_OPT_USE_BVH:
             if (value) {
                 int rc = build_bvh(c);
@@ -1327,7 +1354,7 @@ void rt_free(rt_ctx* c) {
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     c->bvh_nodes.release(); c->bvh_groups.release(); c->bvh_spill.release();
     c->eye_a.release(); c->dir_rinv.release(); c->light_dir_row.release(); c->cone_camera.release();
-    c->bound_lights.release(); c->light_frame.release();
+    c->bound_lights.release(); c->light_frame.release(); c->sphere_any.release(); c->plane_any.release();
     delete c;
 }
 

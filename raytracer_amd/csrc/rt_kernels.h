@@ -131,6 +131,9 @@ struct TraceArgs {
     const float* bound_lights;           // [n_lights][n_regular + 8][4]  point light: cone from the light (axis, cos);
                                          //   directional light: (-2 cu, -2 cv, rho^2 - cu^2 - cv^2, 0) in the light's plane
     const double* light_frame;           // [n_lights][8]  directional light: e1 (3), e2 (3), -O.e1, -O.e2
+    // MODE 0, rays with nothing in common (null = no bounding test):
+    const float* sphere_any;             // [n_regular + 8][4]  bounding sphere: centre, rho^2 - |centre|^2 (+ rounding slack)
+    const float* plane_any;              // [n_regular + 8][4]  the triangle's plane (n, d0), a compact copy of the filter record's head
 };
 
 // Shadow rays are numbered light-major: ray = light * n_hits + hit, so that rays towards one
@@ -414,7 +417,14 @@ typedef __attribute__((address_space(4))) const v4u cv4u;
 // within b_hi * (largest distance to the light) of the plane, or (directional light) |n . dir|
 // <= b_hi.  Once per 64 triangles every lane evaluates that for one of them and a ballot turns
 // the answers into a scalar mask; triangles it names take the triangle test whatever the cone says.
+//
+// PRE = 4: rays with nothing in common (reflection rays).  Squared distance of the sphere's
+// centre from the ray's line, |C - P|^2 - ((C - P).V)^2 / |V|^2 <= rho^2, expanded so that the
+// per-ray parts (P.V, |P|^2, 1 / |V|^2) are computed once per task: nine multiply-adds per ray,
+// no reciprocal; the rounding of the expanded form is part of the radius.  The in-plane-origin
+// case is asked per pair here: a = d0 - n.P from a compact copy of the planes (three more).
 struct PlaneGuard {
+    const float* planes;                 // PRE 4: (n, d0) per triangle, 4 floats each
     const float* records;                // the filter records as plain memory (16 floats per triangle)
     float lx, ly, lz;                    // point light: position; directional light: unit direction
     float limit;                         // point light: b_hi * reach + 2 a_zero; directional light: b_hi (1 + 1e-3)
@@ -487,7 +497,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
             }
         }
     };
-    v16f cones_cur = {}, cones_nxt = {};
+    v16f cones_cur = {}, cones_nxt = {}, planes_cur = {}, planes_nxt = {};
     unsigned long long guard_mask = 0;
     int guard_base = 0;
     for (cbeg = abeg; cbeg < aend; cbeg += CHUNK) {
@@ -503,6 +513,10 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                 // the pace of the cone test).  The arrays are readable a batch past their end.
                 if (j0 == cbeg) cones_cur = *(const cv16u*)((const cfloat*)cone + 4 * (size_t)j0);
                 cones_nxt = *(const cv16u*)((const cfloat*)cone + 4 * (size_t)(j0 + RT_BATCH));
+                if (PRE == 4) {
+                    if (j0 == cbeg) planes_cur = *(const cv16u*)((const cfloat*)guard.planes + 4 * (size_t)j0);
+                    planes_nxt = *(const cv16u*)((const cfloat*)guard.planes + 4 * (size_t)(j0 + RT_BATCH));
+                }
                 unsigned int want = 0;
                 if ((PRE == 2 || PRE == 3) && ((j0 - cbeg) & 63) == 0) {
                     const int j = j0 + lane;
@@ -524,7 +538,46 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                     const float ax = cones_cur[4 * jb], ay = cones_cur[4 * jb + 1], az = cones_cur[4 * jb + 2];
                     const v2f cx = {ax, ax}, cy = {ay, ay}, cz = {az, az};
                     v2f d[RPL / 2];
-                    if (PRE == 3) {
+                    if (PRE == 4) {
+                        // az = rho^2 - |C|^2 lives in cones_cur[4 jb + 3]; (hx, hy, hz) = (P.V, |P|^2, 1 / |V|^2)
+                        const v2f m2 = {-2.0f, -2.0f};
+                        v2f t[RPL / 2];
+#pragma unroll
+                        for (int q = 0; q < RPL / 2; q++) t[q] = __builtin_elementwise_fma(cx, L.vx[q], -L.hx[q]);
+#pragma unroll
+                        for (int q = 0; q < RPL / 2; q++) d[q] = cx * L.px[q];
+#pragma unroll
+                        for (int q = 0; q < RPL / 2; q++) t[q] = __builtin_elementwise_fma(cy, L.vy[q], t[q]);
+#pragma unroll
+                        for (int q = 0; q < RPL / 2; q++) d[q] = __builtin_elementwise_fma(cy, L.py[q], d[q]);
+#pragma unroll
+                        for (int q = 0; q < RPL / 2; q++) t[q] = __builtin_elementwise_fma(cz, L.vz[q], t[q]);
+#pragma unroll
+                        for (int q = 0; q < RPL / 2; q++) d[q] = __builtin_elementwise_fma(cz, L.pz[q], d[q]);
+#pragma unroll
+                        for (int q = 0; q < RPL / 2; q++) d[q] = __builtin_elementwise_fma(m2, d[q], L.hy[q]);
+#pragma unroll
+                        for (int q = 0; q < RPL / 2; q++) t[q] = t[q] * t[q];
+#pragma unroll
+                        for (int q = 0; q < RPL / 2; q++) d[q] = __builtin_elementwise_fma(-t[q], L.hz[q], d[q]);
+                        float low = __builtin_fminf(d[0].x, d[0].y);
+#pragma unroll
+                        for (int q = 1; q < RPL / 2; q++) low = __builtin_fminf(__builtin_fminf(low, d[q].x), d[q].y);
+                        // the plane: is any origin in it?
+                        const float nx = planes_cur[4 * jb], ny = planes_cur[4 * jb + 1], nz = planes_cur[4 * jb + 2];
+                        const v2f n0 = {nx, nx}, n1 = {ny, ny}, n2 = {nz, nz}, dd = {planes_cur[4 * jb + 3], planes_cur[4 * jb + 3]};
+                        v2f a[RPL / 2];
+#pragma unroll
+                        for (int q = 0; q < RPL / 2; q++) a[q] = __builtin_elementwise_fma(-n0, L.px[q], dd);
+#pragma unroll
+                        for (int q = 0; q < RPL / 2; q++) a[q] = __builtin_elementwise_fma(-n1, L.py[q], a[q]);
+#pragma unroll
+                        for (int q = 0; q < RPL / 2; q++) a[q] = __builtin_elementwise_fma(-n2, L.pz[q], a[q]);
+                        float a_low = __builtin_fminf(fabsf(a[0].x), fabsf(a[0].y));
+#pragma unroll
+                        for (int q = 1; q < RPL / 2; q++) a_low = __builtin_fminf(__builtin_fminf(a_low, fabsf(a[q].x)), fabsf(a[q].y));
+                        if ((low <= cones_cur[4 * jb + 3]) | (a_low <= fp.a_zero)) want |= 1u << jb;
+                    } else if (PRE == 3) {
 #pragma unroll
                         for (int q = 0; q < RPL / 2; q++) d[q] = __builtin_elementwise_fma(cy, L.hy[q], L.hz[q]);
 #pragma unroll
@@ -566,6 +619,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                     }
                 }
                 cones_cur = cones_nxt;
+                if (PRE == 4) planes_cur = planes_nxt;
             } else {
                 // The record of triangle j+1 is requested before triangle j is evaluated (the
                 // array carries padding records, so j+1 is always readable).
@@ -658,6 +712,7 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
         if (MODE == 0) {
             if (A.shared_origin_a) { shared_kind = 1; shared = (const cfloat*)A.shared_origin_a; }
             if (CONE == 1) { cone_kind = 1; cone = (const cv4f*)A.cone_camera; }
+            if (CONE == 4) { cone_kind = 4; cone = (const cv4f*)A.sphere_any; }
         } else {
             light = __builtin_amdgcn_readfirstlane((int)(rb / blocks_per_light));
             const unsigned int b = rb - (unsigned int)light * blocks_per_light;
@@ -751,6 +806,12 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                         if (CONE != 1) { fx = 0.f; fy = 0.f; fz = 0.f; }
                         gx = 0.f; gy = 0.f; gz = 1.f;
                     }
+                    if (CONE == 4) {
+                        // per-ray parts of the expanded distance test, from the rounded values the test multiplies
+                        ux = (float)((double)fx * gx + (double)fy * gy + (double)fz * gz);
+                        uy = (float)((double)fx * fx + (double)fy * fy + (double)fz * fz);
+                        uz = (float)(1.0 / ((double)gx * gx + (double)gy * gy + (double)gz * gz));
+                    }
                     if (CONE == 2 && cone_kind == 3) {
                         // Every ray of the task has the light's direction (kept in scalar registers);
                         // the direction slots carry the origin in the light's plane instead.
@@ -765,7 +826,7 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                                          L.vx[k / 2].y = gx; L.vy[k / 2].y = gy; L.vz[k / 2].y = gz; }
                             else { L.px[k / 2].x = fx; L.py[k / 2].x = fy; L.pz[k / 2].x = fz;
                                    L.vx[k / 2].x = gx; L.vy[k / 2].x = gy; L.vz[k / 2].x = gz; }
-                            if (CONE == 1) {
+                            if (CONE == 1 || CONE == 4) {
                                 if (k & 1) { L.hx[k / 2].y = ux; L.hy[k / 2].y = uy; L.hz[k / 2].y = uz; }
                                 else { L.hx[k / 2].x = ux; L.hy[k / 2].x = uy; L.hz[k / 2].x = uz; }
                             }
@@ -774,6 +835,7 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                 }
             }
             PlaneGuard guard = {};
+            if (CONE == 4) guard.planes = A.plane_any;
             if (CONE == 2) {
                 float m = reach_max;
                 for (int off = 32; off > 0; off >>= 1) {
@@ -825,6 +887,10 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                     if (axis == 0) RT_RANGE(0, 1, 1);
                     if (axis == 1) RT_RANGE(1, 1, 1);
                     if (axis == 2) RT_RANGE(2, 1, 1);
+                } else if (CONE == 4) {
+                    if (axis == 0) RT_RANGE(0, 0, 4);
+                    if (axis == 1) RT_RANGE(1, 0, 4);
+                    if (axis == 2) RT_RANGE(2, 0, 4);
                 } else if (CONE == 2 && cone_kind == 2) {
                     if (axis == 0) RT_RANGE(0, 0, 2);
                     if (axis == 1) RT_RANGE(1, 0, 2);
