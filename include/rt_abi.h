@@ -101,12 +101,13 @@ typedef enum rt_option {
     RT_OPT_OVERLAP = 7,      /* 1 (default): a level's shadow-ray launches run on an internal stream beside the
                                 next level's nearest-hit launches (joined back into the caller's stream before
                                 the call's last kernel); 0: one stream.  Off while RT_OPT_PROFILE is on */
-    RT_OPT_BOUNDING_TESTS = 8 /* 1 (default): where all rays of a launch pass through one point (camera rays: the
-                                eye; shadow rays: a point light) or are parallel (a directional light), the
-                                brute-force scan first asks whether any ray of a lane can reach the triangle's
-                                bounding sphere (2-3 multiply-adds per ray) and runs the triangle test only then;
-                                0: every pair takes the triangle test.  Needs RT_OPT_SHARED_CONSTANTS.  Frames
-                                are identical either way */
+    RT_OPT_BOUNDING_TESTS = 8 /* 1 (default): the brute-force scan first asks whether any ray of a lane can reach
+                                the triangle's bounding sphere and runs the triangle test only then: 2-3
+                                multiply-adds per ray where all rays of a launch pass through one point (camera
+                                rays: the eye; shadow rays: a point light) or are parallel (a directional
+                                light) -- these need RT_OPT_SHARED_CONSTANTS --, 12 for rays with nothing in
+                                common (reflection rays); 2: only the former; 0: every pair takes the triangle
+                                test.  Frames are identical in all three */
 } rt_option;
 
 /* Counters since rt_upload_scene or the last rt_reset_stats. */

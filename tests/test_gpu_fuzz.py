@@ -154,7 +154,9 @@ def test_every_configuration_equals_exact_only(family, seed, tmp_path):
     in_plane = None
     for form in (1, 2):
         # shared constants with and without the bounding tests in front of the triangle test, then neither
-        for more in ({"SHARED_CONSTANTS": 1}, {"SHARED_CONSTANTS": 1, "BOUNDING_TESTS": 0}, {"SHARED_CONSTANTS": 0}):
+        for more in ({"SHARED_CONSTANTS": 1}, {"SHARED_CONSTANTS": 1, "BOUNDING_TESTS": 2},
+                     {"SHARED_CONSTANTS": 1, "BOUNDING_TESTS": 0}, {"SHARED_CONSTANTS": 0},
+                     {"SHARED_CONSTANTS": 0, "BOUNDING_TESTS": 0}):
             img, st = render(sc, FILTER_FORM=form, **more)
             assert np.array_equal(img, want), (form, more, int((img != want).any(axis=-1).sum()))
             for key in ("rays_reflect", "rays_shadow", "hits"):
