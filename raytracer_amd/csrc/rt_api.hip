@@ -712,7 +712,11 @@ int install_filter(rt_ctx* c, int robust) {
         // point light: cone from the light, and the light's distance from the triangle's plane;
         // directional light: disc in the plane perpendicular to the light's direction, coordinates
         // about the centre of the scene.
-        {
+        // (16 bytes per triangle and light: beyond 2 GiB the table is left out and shadow rays take the
+        // triangle test for every pair)
+        if (c->h_lights.size() * ((size_t)NR + 8) * 16 > ((size_t)2 << 30)) {
+            c->bound_lights.release(); c->light_frame.release();
+        } else {
             const size_t NL = c->h_lights.size(), stride = (size_t)NR + 8;
             std::vector<float> bound(NL * stride * 4, 0.f);
             std::vector<double> frame(std::max<size_t>(NL, 1) * 8, 0.0);

@@ -131,8 +131,11 @@ def test_bounding_tests_change_nothing(name, w, h, depth):
         assert np.array_equal(a, d), form
         assert sd["in_plane_origin_hits"] == sb["in_plane_origin_hits"]
         if sa["flagged_rays"] == sd["flagged_rays"] == sb["flagged_rays"] == 0:
-            # (a ray whose pairs overflow the list is scanned in full, which counts every triangle)
-            assert sa["exact_tests"] <= sd["exact_tests"] <= sb["exact_tests"]
+            # A bounding test can only take pairs away from the list.  (How many depends on which
+            # rays share a lane, i.e. on the order in which the waves of k_hit appended their hits,
+            # so the two bounded counts are not comparable with each other; a ray whose pairs
+            # overflow the list is scanned in full, which counts every triangle.)
+            assert sa["exact_tests"] <= sb["exact_tests"] and sd["exact_tests"] <= sb["exact_tests"]
     c, _ = gpu_render(sc, exact_only=True)
     assert np.array_equal(a, c)
 
