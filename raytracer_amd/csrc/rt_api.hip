@@ -344,8 +344,8 @@ int launch_trace(rt_ctx* c, TraceArgs A, hipStream_t st, bool camera_rays = fals
                 if (c->robust) hipLaunchKernelGGL((k_filter<0, RT_RPL, true, 1>), grid, block, 0, st, dsc, records, A);
                 else hipLaunchKernelGGL((k_filter<0, RT_RPL, false, 1>), grid, block, 0, st, dsc, records, A);
             } else if (MODE == 0 && A.sphere_any) {
-                if (c->robust) hipLaunchKernelGGL((k_filter<0, RT_RPL, true, 4>), grid, block, 0, st, dsc, records, A);
-                else hipLaunchKernelGGL((k_filter<0, RT_RPL, false, 4>), grid, block, 0, st, dsc, records, A);
+                if (c->robust) hipLaunchKernelGGL((k_filter<0, RT_RPL_ANY, true, 4>), grid, block, 0, st, dsc, records, A);
+                else hipLaunchKernelGGL((k_filter<0, RT_RPL_ANY, false, 4>), grid, block, 0, st, dsc, records, A);
             } else if (MODE == 1 && A.bound_lights) {
                 if (c->robust) hipLaunchKernelGGL((k_filter<1, RT_RPL, true, 2>), grid, block, 0, st, dsc, records, A);
                 else hipLaunchKernelGGL((k_filter<1, RT_RPL, false, 2>), grid, block, 0, st, dsc, records, A);
