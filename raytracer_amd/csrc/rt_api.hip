@@ -144,6 +144,7 @@ struct rt_ctx {
     DevBuf<int32_t> lvl_parent, lvl_obj;   // [levels][cap]
     DevBuf<double> lvl_phong, lvl_child;   // [levels][3][cap]
     DevBuf<uint32_t> counts;       // [levels + 1]
+    DevBuf<uint32_t> hit_offsets;  // [aux_grid + 1]: k_hit_offsets -> k_hit
     DevBuf<uint8_t> ray_flags[2];     // [cap * max(1, n_lights)]
     // scratch of the trace launches, one set per kind of query ([0] nearest hit, [1] shadow) so
     // that a level's shadow launches can run beside the next level's nearest-hit launches
@@ -247,6 +248,8 @@ int ensure_workspace(rt_ctx* c) {
     HIP_TRY(c->lvl_phong.alloc((size_t)levels * 3 * want));
     HIP_TRY(c->lvl_child.alloc((size_t)levels * 3 * want));
     HIP_TRY(c->counts.alloc(levels + 2));
+    HIP_TRY(c->hit_offsets.alloc((size_t)c->aux_grid + 1));
+    HIP_TRY(hipMemset(c->hit_offsets.p, 0, ((size_t)c->aux_grid + 1) * sizeof(uint32_t)));   // (its last entry counts finished blocks and must start at zero)
     const size_t shadow_rays = want * (size_t)std::max(1, c->hs.n_lights);
     if (shadow_rays >= (1ull << 31)) return fail(RT_ERR_RANGE, "pass too large: lower RT_OPT_PASS_PIXELS");
     // room for 16 listed pairs per ray of the largest launch (a few are typical), 8 B each
@@ -468,8 +471,10 @@ int run_pass(rt_ctx* c, PassDesc pd, int nrows, hipStream_t st) {
         if (overlap && k >= 2) HIP_TRY(hipStreamWaitEvent(st, c->ev_phong[k - 2], 0));
         HitArgs ha{};
         ha.sc = dsc; ha.cur = q[cur]; ha.next = q[nxt]; ha.keys = c->keys[cur].p; ha.next_keys = c->keys[nxt].p;
-        ha.n_rays = c->counts.p + k; ha.n_hits = c->counts.p + k + 1; ha.lvl = lvl; ha.aux = aux;
+        ha.n_rays = c->counts.p + k; ha.hit_offsets = c->hit_offsets.p; ha.lvl = lvl; ha.aux = aux;
         ha.occluded = occl; ha.occl_words = c->occl_words;
+        hipLaunchKernelGGL(k_hit_offsets, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, (const unsigned long long*)c->keys[cur].p,
+                           (const uint32_t*)(c->counts.p + k), c->hit_offsets.p, c->counts.p + k + 1);
         hipLaunchKernelGGL(k_hit, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, ha);
         HIP_TRY(hipGetLastError());
         if (overlap) {
@@ -1351,7 +1356,7 @@ void rt_free(rt_ctx* c) {
     for (int i = 0; i < 2; i++) { c->rayq[i].release(); c->keys[i].release(); }
     for (int i = 0; i < 2; i++) { c->aux[i].release(); c->occluded[i].release(); }
     c->pixel_of_ray.release(); c->lvl_parent.release();
-    c->lvl_obj.release(); c->lvl_phong.release(); c->lvl_child.release(); c->counts.release();
+    c->lvl_obj.release(); c->lvl_phong.release(); c->lvl_child.release(); c->counts.release(); c->hit_offsets.release();
     for (int i = 0; i < 2; i++) { c->ray_flags[i].release(); c->pairs[i].release(); c->pair_count[i].release(); }
     for (auto e : c->ev_hit) (void)hipEventDestroy(e);
     for (auto e : c->ev_phong) (void)hipEventDestroy(e);

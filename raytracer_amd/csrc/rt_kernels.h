@@ -1077,30 +1077,105 @@ struct HitArgs {
     const unsigned long long* keys;
     unsigned long long* next_keys;
     const uint32_t* n_rays;
-    uint32_t* n_hits;                    // zeroed by the host before the launch
+    const uint32_t* hit_offsets;         // per block: hits of the blocks before it (k_hit_offsets, same grid)
     LevelStore lvl;
     HitAux aux;
     uint32_t* occluded;
     int32_t occl_words;
 };
 
+// The hits keep the order of their rays (ray i before ray j => its hit before j's): rays that
+// are neighbours on the film stay neighbours in the next level's queue and in the shadow
+// queue, which is what the bounding tests of k_filter live on (a task's 512 rays ask for few
+// triangles when they run close together).  Every block owns a contiguous range of the queue.
+// k_hit_offsets counts the hits per block; the block that finishes last turns the counts into
+// exclusive offsets and publishes the total as the next queue's length.
+__device__ __forceinline__ unsigned int hit_range_length(unsigned int n, unsigned int n_blocks) {
+    const unsigned int per = (n + n_blocks - 1) / n_blocks;
+    return (per + RT_BLOCK - 1) / RT_BLOCK * RT_BLOCK;
+}
+
+__global__ void __launch_bounds__(RT_BLOCK)
+k_hit_offsets(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ n_rays, uint32_t* offsets,
+              uint32_t* n_hits) {
+    // offsets[0 .. gridDim.x): per block; offsets[gridDim.x]: blocks finished so far (zero between launches)
+    __shared__ unsigned int part[RT_BLOCK];
+    __shared__ bool last_block;
+    const unsigned int n = *n_rays, G = gridDim.x;
+    const unsigned int per = hit_range_length(n, G);
+    const unsigned int begin = blockIdx.x * per;
+    unsigned int mine = 0;
+    for (unsigned int it = 0; it < per; it += RT_BLOCK) {
+        const unsigned int i = begin + it + threadIdx.x;
+        if (i < n && keys[i] != RT_MISS_KEY) mine++;
+    }
+    part[threadIdx.x] = mine;
+    __syncthreads();
+    for (int off = RT_BLOCK / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&offsets[blockIdx.x], part[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last_block = atomicAdd(&offsets[G], 1u) == G - 1u;
+    }
+    __syncthreads();
+    if (!last_block) return;
+    __threadfence();
+    // exclusive scan of the G counts by this block: a run of consecutive entries per thread
+    const unsigned int run = (G + RT_BLOCK - 1) / RT_BLOCK;
+    const unsigned int first = threadIdx.x * run;
+    unsigned int sum = 0;
+    for (unsigned int k = first; k < first + run && k < G; k++)
+        sum += __hip_atomic_load(&offsets[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < RT_BLOCK; off <<= 1) {            // inclusive scan of the per-thread sums
+        unsigned int add = ((int)threadIdx.x >= off) ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    unsigned int at = part[threadIdx.x] - sum;
+    for (unsigned int k = first; k < first + run && k < G; k++) {
+        const unsigned int cnt = __hip_atomic_load(&offsets[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        offsets[k] = at;
+        at += cnt;
+    }
+    if (threadIdx.x == RT_BLOCK - 1) { *n_hits = part[RT_BLOCK - 1]; offsets[G] = 0u; }
+}
+
 __global__ void __launch_bounds__(RT_BLOCK)
 k_hit(HitArgs A) {
     const DevScene* __restrict__ sc = A.sc;
+    __shared__ unsigned int wave_hits[RT_BLOCK / RT_WAVE];
     const unsigned int n = *A.n_rays;
     const int lane = threadIdx.x & (RT_WAVE - 1);
-    const unsigned int stride = gridDim.x * blockDim.x;
-    const unsigned int n_round = (n + stride - 1) / stride * stride;
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+    const int wave = threadIdx.x / RT_WAVE;
+    const unsigned int per = hit_range_length(n, gridDim.x);
+    const unsigned int begin = blockIdx.x * per;
+    unsigned int block_base = A.hit_offsets[blockIdx.x];
+    for (unsigned int it = 0; it < per && begin + it < n; it += RT_BLOCK) {
+        const unsigned int i = begin + it + threadIdx.x;
         unsigned long long key = (i < n) ? A.keys[i] : RT_MISS_KEY;
         const bool hit = key != RT_MISS_KEY;
-        // wave-level compaction: one atomic per wave
+        // position of the hit: hits of earlier blocks, of earlier iterations, of earlier waves, of earlier lanes
         const unsigned long long ballot = __ballot(hit);
-        unsigned int base = 0;
-        if (lane == 0 && ballot) base = atomicAdd(A.n_hits, (unsigned int)__popcll(ballot));
-        base = __shfl(base, 0);
+        if (lane == 0) wave_hits[wave] = (unsigned int)__popcll(ballot);
+        __syncthreads();
+        unsigned int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < RT_BLOCK / RT_WAVE; w++) {
+            const unsigned int cnt = wave_hits[w];
+            if (w < wave) before += cnt;
+            total += cnt;
+        }
+        __syncthreads();
+        const unsigned int h = block_base + before + (unsigned int)__popcll(ballot & ((1ull << lane) - 1ull));
+        block_base += total;
         if (!hit) continue;
-        const unsigned int h = base + (unsigned int)__popcll(ballot & ((1ull << lane) - 1ull));
         const int obj = (int)(unsigned int)(key & 0xffffffffu);
         const int xf = sc->obj_transform[obj];
         const double* X = sc->xforms + 48 * (size_t)xf;
