@@ -502,6 +502,8 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
         }
     };
     v16f cones_cur = {}, cones_nxt = {}, planes_cur = {}, planes_nxt = {};
+    if (PRE) cones_nxt = *(const cv16u*)((const cfloat*)cone + 4 * (size_t)abeg);
+    if (PRE == 4) planes_nxt = *(const cv16u*)((const cfloat*)guard.planes + 4 * (size_t)abeg);
     unsigned long long guard_mask = 0;
     int guard_base = 0;
     for (cbeg = abeg; cbeg < aend; cbeg += CHUNK) {
@@ -515,13 +517,19 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                 // per batch asks whether any lane wants any of the four triangles, and only then
                 // is a triangle record fetched (the scalar cache cannot feed 64-byte records at
                 // the pace of the cone test).  The arrays are readable a batch past their end.
-                if (j0 == cbeg) cones_cur = *(const cv16u*)((const cfloat*)cone + 4 * (size_t)j0);
+                // (Scalar loads return out of order, so waiting for one waits for all: the only load
+                // in flight while a batch is evaluated must be the next batch's.  The first batch's
+                // records are requested before the loops, batches follow each other without gaps.)
+                cones_cur = cones_nxt;
                 cones_nxt = *(const cv16u*)((const cfloat*)cone + 4 * (size_t)(j0 + RT_BATCH));
                 if (PRE == 4) {
-                    if (j0 == cbeg) planes_cur = *(const cv16u*)((const cfloat*)guard.planes + 4 * (size_t)j0);
+                    planes_cur = planes_nxt;
                     planes_nxt = *(const cv16u*)((const cfloat*)guard.planes + 4 * (size_t)(j0 + RT_BATCH));
                 }
-                unsigned int want = 0;
+                // (one comparison per triangle, kept as a lane mask; the four are merged on the scalar
+                // unit and turned into per-lane bits only inside the branch)
+                bool wants[RT_BATCH];
+                unsigned int named = 0;
                 if ((PRE == 2 || PRE == 3) && ((j0 - cbeg) & 63) == 0) {
                     const int j = j0 + lane;
                     bool named = false;
@@ -536,7 +544,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                     guard_mask = __ballot(named);
                     guard_base = j0;
                 }
-                if (PRE == 2 || PRE == 3) want = (unsigned int)(guard_mask >> (j0 - guard_base)) & ((1u << RT_BATCH) - 1u);
+                if (PRE == 2 || PRE == 3) named = (unsigned int)(guard_mask >> (j0 - guard_base)) & ((1u << RT_BATCH) - 1u);
 #pragma unroll
                 for (int jb = 0; jb < RT_BATCH; jb++) {
                     const float ax = cones_cur[4 * jb], ay = cones_cur[4 * jb + 1], az = cones_cur[4 * jb + 2];
@@ -580,7 +588,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                         float a_low = __builtin_fminf(fabsf(a[0].x), fabsf(a[0].y));
 #pragma unroll
                         for (int q = 1; q < RPL / 2; q++) a_low = __builtin_fminf(__builtin_fminf(a_low, fabsf(a[q].x)), fabsf(a[q].y));
-                        if ((low <= cones_cur[4 * jb + 3]) | (a_low <= fp.a_zero)) want |= 1u << jb;
+                        wants[jb] = (low <= cones_cur[4 * jb + 3]) | (a_low <= fp.a_zero);
                     } else if (PRE == 3) {
 #pragma unroll
                         for (int q = 0; q < RPL / 2; q++) d[q] = __builtin_elementwise_fma(cy, L.hy[q], L.hz[q]);
@@ -589,7 +597,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                         float low = __builtin_fminf(d[0].x, d[0].y);
 #pragma unroll
                         for (int q = 1; q < RPL / 2; q++) low = __builtin_fminf(__builtin_fminf(low, d[q].x), d[q].y);
-                        if (low <= az) want |= 1u << jb;
+                        wants[jb] = low <= az;
                     } else {
                         const v2f* hx = (PRE == 2) ? L.vx : L.hx;         // shadow-ray directions have unit length
                         const v2f* hy = (PRE == 2) ? L.vy : L.hy;
@@ -611,10 +619,16 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                             for (int q = 1; q < RPL / 2; q++) top = __builtin_fmaxf(__builtin_fmaxf(top, d[q].x), d[q].y);
                         }
                         // (cos = -2 where the shared point may lie in the triangle's plane or inside the sphere)
-                        if (top >= cones_cur[4 * jb + 3]) want |= 1u << jb;
+                        wants[jb] = top >= cones_cur[4 * jb + 3];
                     }
                 }
-                if (want != 0) {                                  // rarely true for any lane of the wave
+                bool any_wanted = named != 0;
+#pragma unroll
+                for (int jb = 0; jb < RT_BATCH; jb++) any_wanted |= wants[jb];
+                if (any_wanted) {                                 // rarely true for any lane of the wave
+                    unsigned int want = named;
+#pragma unroll
+                    for (int jb = 0; jb < RT_BATCH; jb++) want |= wants[jb] ? (1u << jb) : 0u;
 #pragma unroll 1
                     for (int jb = 0; jb < RT_BATCH; jb++) {
                         const int j = j0 + jb;
@@ -622,8 +636,6 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                         if ((want >> jb) & 1u) test_triangle(j, filt[j], SHARED ? shared[j] : 0.0f);
                     }
                 }
-                cones_cur = cones_nxt;
-                if (PRE == 4) planes_cur = planes_nxt;
             } else {
                 // The record of triangle j+1 is requested before triangle j is evaluated (the
                 // array carries padding records, so j+1 is always readable).
