@@ -422,6 +422,14 @@ typedef __attribute__((address_space(4))) const v4u cv4u;
 // <= b_hi.  Once per 64 triangles every lane evaluates that for one of them and a ballot turns
 // the answers into a scalar mask; triangles it names take the triangle test whatever the cone says.
 //
+// PRE = 1, 2, 3, one level up: the task's 512 rays are neighbours on the film, so one cone
+// (one disc) bounds them all, and most triangles are out of reach of the whole bundle.  Once
+// per 64 triangles every lane asks that for one triangle -- cones meet when the angle between
+// their axes is at most the sum of their half-angles, discs when their centres are closer than
+// the sum of their radii -- and a ballot turns the answers into a scalar mask: batches of four
+// triangles none of which the bundle can reach (and the plane guard does not name) cost a few
+// scalar instructions.
+//
 // PRE = 4: rays with nothing in common (reflection rays).  Squared distance of the sphere's
 // centre from the ray's line, |C - P|^2 - ((C - P).V)^2 / |V|^2 <= rho^2, expanded so that the
 // per-ray parts (P.V, |P|^2, 1 / |V|^2) are computed once per task: nine multiply-adds per ray,
@@ -435,6 +443,12 @@ struct PlaneGuard {
     float cx, cy, cz, hx, hy, hz;        // box around the task's ray origins (centre, half extents)
     float slack;                         // a_zero
     int point;
+    // What bounds all rays of the task together (PRE 1, 2: a cone of directions -- unit axis, cosine and
+    // sine of its half-angle; PRE 3: a disc of origins in the light's plane -- centre in (bx, by), radius
+    // in bcos).  cull = 0: no such bound (directions too far apart, or not finite).
+    const float* bounds;                 // the table `cone` points to, as plain memory
+    float bx, by, bz, bcos, bsin;
+    int cull;
 };
 
 template <int MODE, int RPL, int AXIS, bool ROBUST, int SHARED, int PRE>
@@ -504,7 +518,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
     v16f cones_cur = {}, cones_nxt = {}, planes_cur = {}, planes_nxt = {};
     if (PRE) cones_nxt = *(const cv16u*)((const cfloat*)cone + 4 * (size_t)abeg);
     if (PRE == 4) planes_nxt = *(const cv16u*)((const cfloat*)guard.planes + 4 * (size_t)abeg);
-    unsigned long long guard_mask = 0;
+    unsigned long long guard_mask = 0, reach_mask = ~0ull;
     int guard_base = 0;
     for (cbeg = abeg; cbeg < aend; cbeg += CHUNK) {
         const int cend = min(cbeg + CHUNK, aend);
@@ -530,20 +544,37 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                 // unit and turned into per-lane bits only inside the branch)
                 bool wants[RT_BATCH];
                 unsigned int named = 0;
-                if ((PRE == 2 || PRE == 3) && ((j0 - cbeg) & 63) == 0) {
+                if (PRE != 4 && ((j0 - cbeg) & 63) == 0) {
                     const int j = j0 + lane;
-                    bool named = false;
-                    if (j < cend) {
+                    bool is_named = false, in_reach = true;
+                    if ((PRE == 2 || PRE == 3) && j < cend) {
                         const float4 pl = *(const float4*)(guard.records + 16 * (size_t)j);      // (n, d0)
                         const float across = pl.x * guard.lx + pl.y * guard.ly + pl.z * guard.lz;
                         const float off = guard.point ? fabsf(pl.w - across) : fabsf(across);
                         const float centre = fabsf(pl.x * guard.cx + pl.y * guard.cy + pl.z * guard.cz - pl.w);
                         const float reach = fabsf(pl.x) * guard.hx + fabsf(pl.y) * guard.hy + fabsf(pl.z) * guard.hz + guard.slack;
-                        named = !(off > guard.limit) && !(centre > reach);
+                        is_named = !(off > guard.limit) && !(centre > reach);
                     }
-                    guard_mask = __ballot(named);
+                    if (guard.cull && j < cend) {
+                        const float4 rec = *(const float4*)(guard.bounds + 4 * (size_t)j);
+                        if (PRE == 3) {
+                            const float cu = -0.5f * rec.x, cv = -0.5f * rec.y;
+                            const float rho = sqrtf(fmaxf(rec.z + cu * cu + cv * cv, 0.0f));      // (radius^2 = k + c.c; inf stays inf)
+                            const float du = cu - guard.bx, dv = cv - guard.by, sum = rho + guard.bcos;
+                            in_reach = !(du * du + dv * dv > sum * sum * (1.0f + 1e-5f));
+                        } else {
+                            float along = rec.x * guard.bx + rec.y * guard.by + rec.z * guard.bz;
+                            if (PRE == 2) along = fabsf(along);
+                            const float ct = rec.w, st = sqrtf(fmaxf(1.0f - ct * ct, 0.0f));
+                            in_reach = (ct < -1.0f) | !(along < ct * guard.bcos - st * guard.bsin - 1e-5f);
+                        }
+                    }
+                    guard_mask = __ballot(is_named);
+                    reach_mask = __ballot(in_reach | is_named);
                     guard_base = j0;
                 }
+                const bool out_of_reach = PRE != 4 && ((reach_mask >> (j0 - guard_base)) & ((1ull << RT_BATCH) - 1ull)) == 0ull;
+                if (!out_of_reach) {
                 if (PRE == 2 || PRE == 3) named = (unsigned int)(guard_mask >> (j0 - guard_base)) & ((1u << RT_BATCH) - 1u);
 #pragma unroll
                 for (int jb = 0; jb < RT_BATCH; jb++) {
@@ -635,6 +666,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                         if (j >= jn) break;
                         if ((want >> jb) & 1u) test_triangle(j, filt[j], SHARED ? shared[j] : 0.0f);
                     }
+                }
                 }
             } else {
                 // The record of triangle j+1 is requested before triangle j is evaluated (the
@@ -881,6 +913,52 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                 guard.cy = uniform_f(0.5f * (box_lo[1] + box_hi[1])); guard.hy = uniform_f(0.5f * (box_hi[1] - box_lo[1]) * (1.0f + 1e-6f));
                 guard.cz = uniform_f(0.5f * (box_lo[2] + box_hi[2])); guard.hz = uniform_f(0.5f * (box_hi[2] - box_lo[2]) * (1.0f + 1e-6f));
                 guard.slack = fp.a_zero;
+            }
+            if (CONE == 1 || CONE == 2) {
+                // what bounds the task's rays together (see filter_range)
+                guard.bounds = (const float*)(const void*)cone;
+                guard.cull = 0;
+                float sx = 0.f, sy = 0.f, sz = 0.f;
+                const v2f* bxs = (CONE == 1) ? L.hx : L.vx;     // camera rays: unit directions; shadow rays: directions, or points in the light's plane
+                const v2f* bys = (CONE == 1) ? L.hy : L.vy;
+                const v2f* bzs = (CONE == 1) ? L.hz : L.vz;
+                const bool disc = CONE == 2 && cone_kind == 3;
+#pragma unroll
+                for (int k = 0; k < RPL / 2; k++) {
+                    sx += bxs[k].x + bxs[k].y; sy += bys[k].x + bys[k].y;
+                    if (!disc) sz += bzs[k].x + bzs[k].y;
+                }
+                for (int off = 32; off > 0; off >>= 1) { sx += __shfl_xor(sx, off); sy += __shfl_xor(sy, off); sz += __shfl_xor(sz, off); }
+                if (disc) {
+                    const float mu = sx * (1.0f / (RT_WAVE * RPL)), mv = sy * (1.0f / (RT_WAVE * RPL));
+                    float far2 = 0.f;
+#pragma unroll
+                    for (int k = 0; k < RPL / 2; k++) {
+                        const float ax = bxs[k].x - mu, ay = bys[k].x - mv, bx2 = bxs[k].y - mu, by2 = bys[k].y - mv;
+                        far2 = fmaxf(far2, fmaxf(ax * ax + ay * ay, bx2 * bx2 + by2 * by2));
+                    }
+                    for (int off = 32; off > 0; off >>= 1) far2 = fmaxf(far2, __shfl_xor(far2, off));
+                    const float rb = sqrtf(far2) * (1.0f + 1e-5f) + 1e-6f * (fabsf(mu) + fabsf(mv));
+                    guard.bx = uniform_f(mu); guard.by = uniform_f(mv); guard.bz = 0.f; guard.bcos = uniform_f(rb); guard.bsin = 0.f;
+                    guard.cull = (rb == rb) ? 1 : 0;            // (a NaN among the points: no bound)
+                } else {
+                    const float inv = 1.0f / sqrtf(sx * sx + sy * sy + sz * sz);
+                    const float ax = sx * inv, ay = sy * inv, az = sz * inv;
+                    float low = 1.0f;
+#pragma unroll
+                    for (int k = 0; k < RPL / 2; k++) {
+                        low = fminf(low, fminf(ax * bxs[k].x + ay * bys[k].x + az * bzs[k].x, ax * bxs[k].y + ay * bys[k].y + az * bzs[k].y));
+                    }
+                    for (int off = 32; off > 0; off >>= 1) low = fminf(low, __shfl_xor(low, off));
+                    // NaN anywhere: the sum, the axis and therefore every product is NaN, and fminf(1, NaN) = 1
+                    const bool finite = (ax == ax) && (ay == ay) && (az == az);
+                    const float cb = low - 4e-6f;
+                    guard.bx = uniform_f(ax); guard.by = uniform_f(ay); guard.bz = uniform_f(az);
+                    guard.bcos = uniform_f(cb);
+                    guard.bsin = uniform_f(sqrtf(fmaxf(1.0f - cb * cb, 0.0f)) + 1e-6f);
+                    guard.cull = (finite && cb > 0.0f) ? 1 : 0;
+                    guard.cull = __builtin_amdgcn_readfirstlane(guard.cull);
+                }
             }
             if (CONE == 1) {
                 // every slot of every lane holds the same origin (the eye in this group's space):
