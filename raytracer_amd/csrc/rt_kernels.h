@@ -544,6 +544,28 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                 // unit and turned into per-lane bits only inside the branch)
                 bool wants[RT_BATCH];
                 unsigned int named = 0;
+                if (PRE == 4 && ((j0 - cbeg) & 63) == 0) {
+                    // Lines through origins within `bsin`... (see PlaneGuard): a line through P with direction V
+                    // stays within |P - m| of the parallel line through m, so the bundle reaches the sphere (C, rho)
+                    // only if a line through m inside the bundle's cone of directions reaches (C, rho + ro).
+                    const int j = j0 + lane;
+                    bool is_named = false, in_reach = true;
+                    if (guard.cull && j < cend) {
+                        const float4 rec = *(const float4*)(guard.bounds + 4 * (size_t)j);        // centre, rho^2 - |C|^2
+                        const float4 pl = *(const float4*)(guard.planes + 4 * (size_t)j);         // (n, d0)
+                        const float rho = sqrtf(fmaxf(rec.w + rec.x * rec.x + rec.y * rec.y + rec.z * rec.z, 0.0f));
+                        const float dx = rec.x - guard.cx, dy = rec.y - guard.cy, dz = rec.z - guard.cz;
+                        const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+                        const float sn = (rho + guard.hx) * (1.0f + 1e-5f) / dist;                // hx: radius of the origins about (cx, cy, cz)
+                        const float along = fabsf(dx * guard.bx + dy * guard.by + dz * guard.bz) / dist;
+                        const float cs = sqrtf(fmaxf(1.0f - sn * sn, 0.0f));
+                        in_reach = !(sn < 0.999f) | !(along < cs * guard.bcos - sn * guard.bsin - 1e-5f);
+                        // the in-plane-origin case: the plane passes through the ball of origins
+                        is_named = !(fabsf(pl.x * guard.cx + pl.y * guard.cy + pl.z * guard.cz - pl.w) > guard.hx + 2.0f * guard.slack);
+                    }
+                    reach_mask = __ballot(in_reach | is_named);
+                    guard_base = j0;
+                }
                 if (PRE != 4 && ((j0 - cbeg) & 63) == 0) {
                     const int j = j0 + lane;
                     bool is_named = false, in_reach = true;
@@ -573,7 +595,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                     reach_mask = __ballot(in_reach | is_named);
                     guard_base = j0;
                 }
-                const bool out_of_reach = PRE != 4 && ((reach_mask >> (j0 - guard_base)) & ((1ull << RT_BATCH) - 1ull)) == 0ull;
+                const bool out_of_reach = ((reach_mask >> (j0 - guard_base)) & ((1ull << RT_BATCH) - 1ull)) == 0ull;
                 if (!out_of_reach) {
                 if (PRE == 2 || PRE == 3) named = (unsigned int)(guard_mask >> (j0 - guard_base)) & ((1u << RT_BATCH) - 1u);
 #pragma unroll
@@ -913,6 +935,43 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                 guard.cy = uniform_f(0.5f * (box_lo[1] + box_hi[1])); guard.hy = uniform_f(0.5f * (box_hi[1] - box_lo[1]) * (1.0f + 1e-6f));
                 guard.cz = uniform_f(0.5f * (box_lo[2] + box_hi[2])); guard.hz = uniform_f(0.5f * (box_hi[2] - box_lo[2]) * (1.0f + 1e-6f));
                 guard.slack = fp.a_zero;
+            }
+            if (CONE == 4) {
+                // what bounds the task's rays together: a ball of origins and a cone of directions
+                guard.bounds = (const float*)(const void*)cone;
+                guard.slack = fp.a_zero;
+                float sx = 0.f, sy = 0.f, sz = 0.f, ox = 0.f, oy = 0.f, oz = 0.f;
+                v2f ux[RPL / 2], uy[RPL / 2], uz[RPL / 2];
+#pragma unroll
+                for (int k = 0; k < RPL / 2; k++) {
+                    const v2f sc2 = {sqrtf(L.hz[k].x), sqrtf(L.hz[k].y)};                       // hz = 1 / |V|^2
+                    ux[k] = L.vx[k] * sc2; uy[k] = L.vy[k] * sc2; uz[k] = L.vz[k] * sc2;
+                    sx += ux[k].x + ux[k].y; sy += uy[k].x + uy[k].y; sz += uz[k].x + uz[k].y;
+                    ox += L.px[k].x + L.px[k].y; oy += L.py[k].x + L.py[k].y; oz += L.pz[k].x + L.pz[k].y;
+                }
+                for (int off = 32; off > 0; off >>= 1) {
+                    sx += __shfl_xor(sx, off); sy += __shfl_xor(sy, off); sz += __shfl_xor(sz, off);
+                    ox += __shfl_xor(ox, off); oy += __shfl_xor(oy, off); oz += __shfl_xor(oz, off);
+                }
+                const float inv = 1.0f / sqrtf(sx * sx + sy * sy + sz * sz);
+                const float ax = sx * inv, ay = sy * inv, az = sz * inv;
+                const float mx = ox * (1.0f / (RT_WAVE * RPL)), my = oy * (1.0f / (RT_WAVE * RPL)), mz = oz * (1.0f / (RT_WAVE * RPL));
+                float low = 1.0f, far2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < RPL / 2; k++) {
+                    low = fminf(low, fminf(ax * ux[k].x + ay * uy[k].x + az * uz[k].x, ax * ux[k].y + ay * uy[k].y + az * uz[k].y));
+                    const float ex = L.px[k].x - mx, ey = L.py[k].x - my, ez = L.pz[k].x - mz;
+                    const float fx2 = L.px[k].y - mx, fy2 = L.py[k].y - my, fz2 = L.pz[k].y - mz;
+                    far2 = fmaxf(far2, fmaxf(ex * ex + ey * ey + ez * ez, fx2 * fx2 + fy2 * fy2 + fz2 * fz2));
+                }
+                for (int off = 32; off > 0; off >>= 1) { low = fminf(low, __shfl_xor(low, off)); far2 = fmaxf(far2, __shfl_xor(far2, off)); }
+                const float ro = sqrtf(far2) * (1.0f + 1e-5f) + 1e-6f * (fabsf(mx) + fabsf(my) + fabsf(mz));
+                const float cb = low - 4e-6f;
+                const bool finite = (ax == ax) && (ay == ay) && (az == az) && (ro == ro);
+                guard.bx = uniform_f(ax); guard.by = uniform_f(ay); guard.bz = uniform_f(az);
+                guard.bcos = uniform_f(cb); guard.bsin = uniform_f(sqrtf(fmaxf(1.0f - cb * cb, 0.0f)) + 1e-6f);
+                guard.cx = uniform_f(mx); guard.cy = uniform_f(my); guard.cz = uniform_f(mz); guard.hx = uniform_f(ro);
+                guard.cull = __builtin_amdgcn_readfirstlane((finite && cb > 0.0f) ? 1 : 0);
             }
             if (CONE == 1 || CONE == 2) {
                 // what bounds the task's rays together (see filter_range)
