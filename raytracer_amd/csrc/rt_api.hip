@@ -344,14 +344,14 @@ int launch_trace(rt_ctx* c, TraceArgs A, hipStream_t st, bool camera_rays = fals
             const dim3 grid(c->filter_grid[MODE]), block(RT_BLOCK);
             const v16f* records = (const v16f*)c->tri_filt.p;
             if (MODE == 0 && A.cone_camera) {
-                if (c->robust) hipLaunchKernelGGL((k_filter<0, RT_RPL, true, 1>), grid, block, 0, st, dsc, records, A);
-                else hipLaunchKernelGGL((k_filter<0, RT_RPL, false, 1>), grid, block, 0, st, dsc, records, A);
+                if (c->robust) hipLaunchKernelGGL((k_filter<0, RT_RPL_SHARED, true, 1>), grid, block, 0, st, dsc, records, A);
+                else hipLaunchKernelGGL((k_filter<0, RT_RPL_SHARED, false, 1>), grid, block, 0, st, dsc, records, A);
             } else if (MODE == 0 && A.sphere_any) {
                 if (c->robust) hipLaunchKernelGGL((k_filter<0, RT_RPL_ANY, true, 4>), grid, block, 0, st, dsc, records, A);
                 else hipLaunchKernelGGL((k_filter<0, RT_RPL_ANY, false, 4>), grid, block, 0, st, dsc, records, A);
             } else if (MODE == 1 && A.bound_lights) {
-                if (c->robust) hipLaunchKernelGGL((k_filter<1, RT_RPL, true, 2>), grid, block, 0, st, dsc, records, A);
-                else hipLaunchKernelGGL((k_filter<1, RT_RPL, false, 2>), grid, block, 0, st, dsc, records, A);
+                if (c->robust) hipLaunchKernelGGL((k_filter<1, RT_RPL_SHARED, true, 2>), grid, block, 0, st, dsc, records, A);
+                else hipLaunchKernelGGL((k_filter<1, RT_RPL_SHARED, false, 2>), grid, block, 0, st, dsc, records, A);
             } else {
                 if (c->robust) hipLaunchKernelGGL((k_filter<MODE, RT_RPL, true, 0>), grid, block, 0, st, dsc, records, A);
                 else hipLaunchKernelGGL((k_filter<MODE, RT_RPL, false, 0>), grid, block, 0, st, dsc, records, A);

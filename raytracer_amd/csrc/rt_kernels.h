@@ -30,6 +30,9 @@
 #define RT_FILTER_MIN_WAVES 1     // waves per SIMD the filter kernel is compiled for (a higher value caps its VGPRs)
 #endif
 #define RT_RPL 8                // rays per lane in the filter kernel
+#ifndef RT_RPL_SHARED
+#define RT_RPL_SHARED 8         // ... in its instances for rays that share a point or a direction
+#endif
 #ifndef RT_RPL_ANY
 #define RT_RPL_ANY 4            // ... in its instance with a bounding test for rays with nothing in common (256 rays per
                                 // task ask for fewer triangles than 512; the scans of camera and shadow rays lose by it)
