@@ -452,6 +452,9 @@ struct PlaneGuard {
     const float* bounds;                 // the table `cone` points to, as plain memory
     float bx, by, bz, bcos, bsin;
     int cull;
+    // PRE 1, 2: neighbours on one scanline fan out in (nearly) one plane through the shared point: unit
+    // normal of that plane (zero: no such plane), sine and cosine of the largest angle a ray makes with it
+    float fx, fy, fz, fsin, fcos;
 };
 
 template <int MODE, int RPL, int AXIS, bool ROBUST, int SHARED, int PRE>
@@ -519,15 +522,26 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
         }
     };
     v16f cones_cur = {}, cones_nxt = {}, planes_cur = {}, planes_nxt = {};
-    if (PRE) cones_nxt = *(const cv16u*)((const cfloat*)cone + 4 * (size_t)abeg);
-    if (PRE == 4) planes_nxt = *(const cv16u*)((const cfloat*)guard.planes + 4 * (size_t)abeg);
+    bool chain_broken = true;                 // cones_nxt / planes_nxt do not hold the batch about to be evaluated
     unsigned long long guard_mask = 0, reach_mask = ~0ull;
     int guard_base = 0;
+    // Per group of 64 triangles every lane looks at one triangle (bounding record, plane); the
+    // records of the next group are requested while this one is scanned.
+    float4 grp_rec = make_float4(0.f, 0.f, 0.f, 0.f), grp_pl = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto request_group = [&](const int jg) {
+        const int j = jg + lane;
+        if (j < aend) {
+            grp_rec = *(const float4*)(guard.bounds + 4 * (size_t)j);
+            if (PRE == 4) grp_pl = *(const float4*)(guard.planes + 4 * (size_t)j);
+            if (PRE == 2 || PRE == 3) grp_pl = *(const float4*)(guard.records + 16 * (size_t)j);
+        }
+    };
+    if (PRE) request_group(abeg);
     for (cbeg = abeg; cbeg < aend; cbeg += CHUNK) {
         const int cend = min(cbeg + CHUNK, aend);
         n_cand = 0;
         for (int j0 = cbeg; j0 < cend; j0 += RT_BATCH) {
-            const int jn = min(j0 + RT_BATCH, cend);
+            int jn = min(j0 + RT_BATCH, cend);
             if (PRE) {
                 // The cone records of a batch (4 x 16 bytes) come in one scalar load, requested a
                 // batch ahead; the four tests run back to back (independent chains), one branch
@@ -537,12 +551,9 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                 // (Scalar loads return out of order, so waiting for one waits for all: the only load
                 // in flight while a batch is evaluated must be the next batch's.  The first batch's
                 // records are requested before the loops, batches follow each other without gaps.)
-                cones_cur = cones_nxt;
-                cones_nxt = *(const cv16u*)((const cfloat*)cone + 4 * (size_t)(j0 + RT_BATCH));
-                if (PRE == 4) {
-                    planes_cur = planes_nxt;
-                    planes_nxt = *(const cv16u*)((const cfloat*)guard.planes + 4 * (size_t)(j0 + RT_BATCH));
-                }
+                // A batch out of reach of the task's bundle does not touch that chain at all, a group
+                // of 64 out of reach is skipped as a whole; the first batch after a gap requests its own
+                // records and waits for them.
                 // (one comparison per triangle, kept as a lane mask; the four are merged on the scalar
                 // unit and turned into per-lane bits only inside the branch)
                 bool wants[RT_BATCH];
@@ -554,8 +565,8 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                     const int j = j0 + lane;
                     bool is_named = false, in_reach = true;
                     if (guard.cull && j < cend) {
-                        const float4 rec = *(const float4*)(guard.bounds + 4 * (size_t)j);        // centre, rho^2 - |C|^2
-                        const float4 pl = *(const float4*)(guard.planes + 4 * (size_t)j);         // (n, d0)
+                        const float4 rec = grp_rec;                                               // centre, rho^2 - |C|^2
+                        const float4 pl = grp_pl;                                                 // (n, d0)
                         const float rho = sqrtf(fmaxf(rec.w + rec.x * rec.x + rec.y * rec.y + rec.z * rec.z, 0.0f));
                         const float dx = rec.x - guard.cx, dy = rec.y - guard.cy, dz = rec.z - guard.cz;
                         const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
@@ -568,12 +579,13 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                     }
                     reach_mask = __ballot(in_reach | is_named);
                     guard_base = j0;
+                    request_group(j0 + 64);
                 }
                 if (PRE != 4 && ((j0 - cbeg) & 63) == 0) {
                     const int j = j0 + lane;
                     bool is_named = false, in_reach = true;
                     if ((PRE == 2 || PRE == 3) && j < cend) {
-                        const float4 pl = *(const float4*)(guard.records + 16 * (size_t)j);      // (n, d0)
+                        const float4 pl = grp_pl;                                                // (n, d0)
                         const float across = pl.x * guard.lx + pl.y * guard.ly + pl.z * guard.lz;
                         const float off = guard.point ? fabsf(pl.w - across) : fabsf(across);
                         const float centre = fabsf(pl.x * guard.cx + pl.y * guard.cy + pl.z * guard.cz - pl.w);
@@ -581,7 +593,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                         is_named = !(off > guard.limit) && !(centre > reach);
                     }
                     if (guard.cull && j < cend) {
-                        const float4 rec = *(const float4*)(guard.bounds + 4 * (size_t)j);
+                        const float4 rec = grp_rec;
                         if (PRE == 3) {
                             const float cu = -0.5f * rec.x, cv = -0.5f * rec.y;
                             const float rho = sqrtf(fmaxf(rec.z + cu * cu + cv * cv, 0.0f));      // (radius^2 = k + c.c; inf stays inf)
@@ -592,14 +604,38 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                             if (PRE == 2) along = fabsf(along);
                             const float ct = rec.w, st = sqrtf(fmaxf(1.0f - ct * ct, 0.0f));
                             in_reach = (ct < -1.0f) | !(along < ct * guard.bcos - st * guard.bsin - 1e-5f);
+                            // ... and the sphere's axis may leave the fan's plane by at most the two angles together
+                            const float aside = fabsf(rec.x * guard.fx + rec.y * guard.fy + rec.z * guard.fz);
+                            const bool in_fan = (ct < -1.0f) | !(ct * guard.fcos - st * guard.fsin > 0.0f) |
+                                                !(aside > st * guard.fcos + ct * guard.fsin + 1e-5f);
+                            in_reach &= in_fan;
                         }
                     }
                     guard_mask = __ballot(is_named);
                     reach_mask = __ballot(in_reach | is_named);
                     guard_base = j0;
+                    request_group(j0 + 64);
+                }
+                if (((j0 - cbeg) & 63) == 0 && reach_mask == 0ull) {
+                    // the whole group is out of reach: on to the next one (or to the end of the chunk)
+                    j0 = min(j0 + 64, cend) - RT_BATCH;
+                    jn = j0 + RT_BATCH;
+                    chain_broken = true;
                 }
                 const bool out_of_reach = ((reach_mask >> (j0 - guard_base)) & ((1ull << RT_BATCH) - 1ull)) == 0ull;
+                if (out_of_reach) chain_broken = true;
                 if (!out_of_reach) {
+                if (chain_broken) {
+                    cones_nxt = *(const cv16u*)((const cfloat*)cone + 4 * (size_t)j0);
+                    if (PRE == 4) planes_nxt = *(const cv16u*)((const cfloat*)guard.planes + 4 * (size_t)j0);
+                    chain_broken = false;
+                }
+                cones_cur = cones_nxt;
+                cones_nxt = *(const cv16u*)((const cfloat*)cone + 4 * (size_t)(j0 + RT_BATCH));
+                if (PRE == 4) {
+                    planes_cur = planes_nxt;
+                    planes_nxt = *(const cv16u*)((const cfloat*)guard.planes + 4 * (size_t)(j0 + RT_BATCH));
+                }
                 if (PRE == 2 || PRE == 3) named = (unsigned int)(guard_mask >> (j0 - guard_base)) & ((1u << RT_BATCH) - 1u);
 #pragma unroll
                 for (int jb = 0; jb < RT_BATCH; jb++) {
@@ -1020,6 +1056,25 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                     guard.bsin = uniform_f(sqrtf(fmaxf(1.0f - cb * cb, 0.0f)) + 1e-6f);
                     guard.cull = (finite && cb > 0.0f) ? 1 : 0;
                     guard.cull = __builtin_amdgcn_readfirstlane(guard.cull);
+                    // the fan: plane through the shared point spanned by the task's first and last direction
+                    const float f0x = uniform_f(bxs[0].x), f0y = uniform_f(bys[0].x), f0z = uniform_f(bzs[0].x);
+                    const float l0x = __shfl(bxs[RPL / 2 - 1].y, RT_WAVE - 1), l0y = __shfl(bys[RPL / 2 - 1].y, RT_WAVE - 1),
+                                l0z = __shfl(bzs[RPL / 2 - 1].y, RT_WAVE - 1);
+                    float nx = f0y * l0z - f0z * l0y, ny = f0z * l0x - f0x * l0z, nz = f0x * l0y - f0y * l0x;
+                    const float nl = sqrtf(nx * nx + ny * ny + nz * nz);
+                    nx /= nl; ny /= nl; nz /= nl;
+                    float wide = 0.f;
+#pragma unroll
+                    for (int k = 0; k < RPL / 2; k++) {
+                        wide = fmaxf(wide, fmaxf(fabsf(nx * bxs[k].x + ny * bys[k].x + nz * bzs[k].x),
+                                                 fabsf(nx * bxs[k].y + ny * bys[k].y + nz * bzs[k].y)));
+                    }
+                    for (int off = 32; off > 0; off >>= 1) wide = fmaxf(wide, __shfl_xor(wide, off));
+                    const float sg = wide * (1.0f + 1e-5f) + 4e-6f;
+                    const bool fan = (nx == nx) && (ny == ny) && (nz == nz) && nl > 1e-6f && sg < 0.5f;   // (NaN: no fan)
+                    guard.fx = uniform_f(fan ? nx : 0.f); guard.fy = uniform_f(fan ? ny : 0.f); guard.fz = uniform_f(fan ? nz : 0.f);
+                    guard.fsin = uniform_f(fan ? sg : 0.f);
+                    guard.fcos = uniform_f(fan ? sqrtf(1.0f - sg * sg) * (1.0f - 1e-6f) : 1.0f);
                 }
             }
             if (CONE == 1) {
