@@ -784,7 +784,12 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
     // Tasks = (block of 64*RPL rays) x (part of the triangle range), handed out through a
     // global counter.  Enough parts that every wave gets several tasks: short tasks keep the
     // chip full until the end of the launch.
-    int max_split = (NR + 127) / 128;
+    // (with the bounding tests a triangle costs a task a fraction of what loading its rays costs:
+    // larger parts)
+#ifndef RT_MIN_PART_BOUNDED
+#define RT_MIN_PART_BOUNDED 512
+#endif
+    int max_split = CONE ? (NR + RT_MIN_PART_BOUNDED - 1) / RT_MIN_PART_BOUNDED : (NR + 127) / 128;
     int split = 1;
     if (n_ray_blocks < 8u * n_waves) {
         split = (int)((8u * n_waves + n_ray_blocks - 1) / n_ray_blocks);
