@@ -455,6 +455,10 @@ struct PlaneGuard {
     // PRE 1, 2: neighbours on one scanline fan out in (nearly) one plane through the shared point: unit
     // normal of that plane (zero: no such plane), sine and cosine of the largest angle a ray makes with it
     float fx, fy, fz, fsin, fcos;
+    // PRE 4: one bundle per pair of ray slots (128 consecutive rays of the queue): ball of origins (centre,
+    // radius) and cone of directions (unit axis, cosine and sine of the half-angle); on = 0: no bound
+    float qm[4][4], qa[4][5];
+    int qon[4];
 };
 
 template <int MODE, int RPL, int AXIS, bool ROBUST, int SHARED, int PRE>
@@ -524,6 +528,9 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
     v16f cones_cur = {}, cones_nxt = {}, planes_cur = {}, planes_nxt = {};
     bool chain_broken = true;                 // cones_nxt / planes_nxt do not hold the batch about to be evaluated
     unsigned long long guard_mask = 0, reach_mask = ~0ull;
+    unsigned long long pair_mask[RPL / 2];    // PRE 4: per pair of ray slots, the triangles of the group its bundle can reach
+#pragma unroll
+    for (int q = 0; q < RPL / 2; q++) pair_mask[q] = ~0ull;
     int guard_base = 0;
     // Per group of 64 triangles every lane looks at one triangle (bounding record, plane); the
     // records of the next group are requested while this one is scanned.
@@ -559,25 +566,32 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                 bool wants[RT_BATCH];
                 unsigned int named = 0;
                 if (PRE == 4 && ((j0 - cbeg) & 63) == 0) {
-                    // Lines through origins within `bsin`... (see PlaneGuard): a line through P with direction V
-                    // stays within |P - m| of the parallel line through m, so the bundle reaches the sphere (C, rho)
-                    // only if a line through m inside the bundle's cone of directions reaches (C, rho + ro).
+                    // A line through P with direction V stays within |P - m| of the parallel line through m, so
+                    // a bundle (origins within ro of m, directions within a cone) reaches the sphere (C, rho) only
+                    // if a line through m inside that cone reaches (C, rho + ro).  In-plane-origin case: the
+                    // triangle's plane passes through the ball of origins.
                     const int j = j0 + lane;
-                    bool is_named = false, in_reach = true;
-                    if (guard.cull && j < cend) {
-                        const float4 rec = grp_rec;                                               // centre, rho^2 - |C|^2
-                        const float4 pl = grp_pl;                                                 // (n, d0)
-                        const float rho = sqrtf(fmaxf(rec.w + rec.x * rec.x + rec.y * rec.y + rec.z * rec.z, 0.0f));
-                        const float dx = rec.x - guard.cx, dy = rec.y - guard.cy, dz = rec.z - guard.cz;
-                        const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
-                        const float sn = (rho + guard.hx) * (1.0f + 1e-5f) / dist;                // hx: radius of the origins about (cx, cy, cz)
-                        const float along = fabsf(dx * guard.bx + dy * guard.by + dz * guard.bz) / dist;
-                        const float cs = sqrtf(fmaxf(1.0f - sn * sn, 0.0f));
-                        in_reach = !(sn < 0.999f) | !(along < cs * guard.bcos - sn * guard.bsin - 1e-5f);
-                        // the in-plane-origin case: the plane passes through the ball of origins
-                        is_named = !(fabsf(pl.x * guard.cx + pl.y * guard.cy + pl.z * guard.cz - pl.w) > guard.hx + 2.0f * guard.slack);
+                    const float4 rec = grp_rec;                                                   // centre, rho^2 - |C|^2
+                    const float4 pl = grp_pl;                                                     // (n, d0)
+                    const float rho = sqrtf(fmaxf(rec.w + rec.x * rec.x + rec.y * rec.y + rec.z * rec.z, 0.0f));
+                    reach_mask = 0ull;
+#pragma unroll
+                    for (int q = 0; q < RPL / 2; q++) {
+                        bool live = true;
+                        if (guard.qon[q] && j < cend) {
+                            const float dx = rec.x - guard.qm[q][0], dy = rec.y - guard.qm[q][1], dz = rec.z - guard.qm[q][2];
+                            const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+                            const float sn = (rho + guard.qm[q][3]) * (1.0f + 1e-5f) / dist;
+                            const float along = fabsf(dx * guard.qa[q][0] + dy * guard.qa[q][1] + dz * guard.qa[q][2]) / dist;
+                            const float cs = sqrtf(fmaxf(1.0f - sn * sn, 0.0f));
+                            const bool in_reach = !(sn < 0.999f) | !(along < cs * guard.qa[q][3] - sn * guard.qa[q][4] - 1e-5f);
+                            const bool is_named = !(fabsf(pl.x * guard.qm[q][0] + pl.y * guard.qm[q][1] + pl.z * guard.qm[q][2] - pl.w) >
+                                                    guard.qm[q][3] + 2.0f * guard.slack);
+                            live = in_reach | is_named;
+                        }
+                        pair_mask[q] = __ballot(live);
+                        reach_mask |= pair_mask[q];
                     }
-                    reach_mask = __ballot(in_reach | is_named);
                     guard_base = j0;
                     request_group(j0 + 64);
                 }
@@ -643,44 +657,8 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                     const v2f cx = {ax, ax}, cy = {ay, ay}, cz = {az, az};
                     v2f d[RPL / 2];
                     if (PRE == 4) {
-                        // az = rho^2 - |C|^2 lives in cones_cur[4 jb + 3]; (hx, hy, hz) = (P.V, |P|^2, 1 / |V|^2)
-                        const v2f m2 = {-2.0f, -2.0f};
-                        v2f t[RPL / 2];
-#pragma unroll
-                        for (int q = 0; q < RPL / 2; q++) t[q] = __builtin_elementwise_fma(cx, L.vx[q], -L.hx[q]);
-#pragma unroll
-                        for (int q = 0; q < RPL / 2; q++) d[q] = cx * L.px[q];
-#pragma unroll
-                        for (int q = 0; q < RPL / 2; q++) t[q] = __builtin_elementwise_fma(cy, L.vy[q], t[q]);
-#pragma unroll
-                        for (int q = 0; q < RPL / 2; q++) d[q] = __builtin_elementwise_fma(cy, L.py[q], d[q]);
-#pragma unroll
-                        for (int q = 0; q < RPL / 2; q++) t[q] = __builtin_elementwise_fma(cz, L.vz[q], t[q]);
-#pragma unroll
-                        for (int q = 0; q < RPL / 2; q++) d[q] = __builtin_elementwise_fma(cz, L.pz[q], d[q]);
-#pragma unroll
-                        for (int q = 0; q < RPL / 2; q++) d[q] = __builtin_elementwise_fma(m2, d[q], L.hy[q]);
-#pragma unroll
-                        for (int q = 0; q < RPL / 2; q++) t[q] = t[q] * t[q];
-#pragma unroll
-                        for (int q = 0; q < RPL / 2; q++) d[q] = __builtin_elementwise_fma(-t[q], L.hz[q], d[q]);
-                        float low = __builtin_fminf(d[0].x, d[0].y);
-#pragma unroll
-                        for (int q = 1; q < RPL / 2; q++) low = __builtin_fminf(__builtin_fminf(low, d[q].x), d[q].y);
-                        // the plane: is any origin in it?
-                        const float nx = planes_cur[4 * jb], ny = planes_cur[4 * jb + 1], nz = planes_cur[4 * jb + 2];
-                        const v2f n0 = {nx, nx}, n1 = {ny, ny}, n2 = {nz, nz}, dd = {planes_cur[4 * jb + 3], planes_cur[4 * jb + 3]};
-                        v2f a[RPL / 2];
-#pragma unroll
-                        for (int q = 0; q < RPL / 2; q++) a[q] = __builtin_elementwise_fma(-n0, L.px[q], dd);
-#pragma unroll
-                        for (int q = 0; q < RPL / 2; q++) a[q] = __builtin_elementwise_fma(-n1, L.py[q], a[q]);
-#pragma unroll
-                        for (int q = 0; q < RPL / 2; q++) a[q] = __builtin_elementwise_fma(-n2, L.pz[q], a[q]);
-                        float a_low = __builtin_fminf(fabsf(a[0].x), fabsf(a[0].y));
-#pragma unroll
-                        for (int q = 1; q < RPL / 2; q++) a_low = __builtin_fminf(__builtin_fminf(a_low, fabsf(a[q].x)), fabsf(a[q].y));
-                        wants[jb] = (low <= cones_cur[4 * jb + 3]) | (a_low <= fp.a_zero);
+                        // (evaluated below, pair by pair)
+                        wants[jb] = false;
                     } else if (PRE == 3) {
 #pragma unroll
                         for (int q = 0; q < RPL / 2; q++) d[q] = __builtin_elementwise_fma(cy, L.hy[q], L.hz[q]);
@@ -713,6 +691,53 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                         // (cos = -2 where the shared point may lie in the triangle's plane or inside the sphere)
                         wants[jb] = top >= cones_cur[4 * jb + 3];
                     }
+                }
+                if (PRE == 4) {
+                    // (hx, hy, hz) = (P.V, |P|^2, 1 / |V|^2); the sphere record's fourth entry is rho^2 - |C|^2.
+                    // A pair of ray slots whose bundle reaches none of the four triangles sits the batch out.
+                    float low[RT_BATCH], a_low[RT_BATCH];
+#pragma unroll
+                    for (int jb = 0; jb < RT_BATCH; jb++) { low[jb] = INFINITY; a_low[jb] = INFINITY; }
+                    const v2f m2 = {-2.0f, -2.0f};
+#pragma unroll
+                    for (int q = 0; q < RPL / 2; q++) {
+                        if (((pair_mask[q] >> (j0 - guard_base)) & ((1ull << RT_BATCH) - 1ull)) == 0ull) continue;
+                        v2f t[RT_BATCH], d[RT_BATCH], a[RT_BATCH];
+#pragma unroll
+                        for (int jb = 0; jb < RT_BATCH; jb++) {
+                            const float cx1 = cones_cur[4 * jb], nx1 = planes_cur[4 * jb];
+                            const v2f cx = {cx1, cx1}, n0 = {nx1, nx1}, dd = {planes_cur[4 * jb + 3], planes_cur[4 * jb + 3]};
+                            t[jb] = __builtin_elementwise_fma(cx, L.vx[q], -L.hx[q]);
+                            d[jb] = cx * L.px[q];
+                            a[jb] = __builtin_elementwise_fma(-n0, L.px[q], dd);
+                        }
+#pragma unroll
+                        for (int jb = 0; jb < RT_BATCH; jb++) {
+                            const float cy1 = cones_cur[4 * jb + 1], ny1 = planes_cur[4 * jb + 1];
+                            const v2f cy = {cy1, cy1}, n1 = {ny1, ny1};
+                            t[jb] = __builtin_elementwise_fma(cy, L.vy[q], t[jb]);
+                            d[jb] = __builtin_elementwise_fma(cy, L.py[q], d[jb]);
+                            a[jb] = __builtin_elementwise_fma(-n1, L.py[q], a[jb]);
+                        }
+#pragma unroll
+                        for (int jb = 0; jb < RT_BATCH; jb++) {
+                            const float cz1 = cones_cur[4 * jb + 2], nz1 = planes_cur[4 * jb + 2];
+                            const v2f cz = {cz1, cz1}, n2 = {nz1, nz1};
+                            t[jb] = __builtin_elementwise_fma(cz, L.vz[q], t[jb]);
+                            d[jb] = __builtin_elementwise_fma(cz, L.pz[q], d[jb]);
+                            a[jb] = __builtin_elementwise_fma(-n2, L.pz[q], a[jb]);
+                        }
+#pragma unroll
+                        for (int jb = 0; jb < RT_BATCH; jb++) {
+                            d[jb] = __builtin_elementwise_fma(m2, d[jb], L.hy[q]);
+                            t[jb] = t[jb] * t[jb];
+                            d[jb] = __builtin_elementwise_fma(-t[jb], L.hz[q], d[jb]);
+                            low[jb] = __builtin_fminf(__builtin_fminf(low[jb], d[jb].x), d[jb].y);
+                            a_low[jb] = __builtin_fminf(__builtin_fminf(a_low[jb], fabsf(a[jb].x)), fabsf(a[jb].y));
+                        }
+                    }
+#pragma unroll
+                    for (int jb = 0; jb < RT_BATCH; jb++) wants[jb] = (low[jb] <= cones_cur[4 * jb + 3]) | (a_low[jb] <= fp.a_zero);
                 }
                 bool any_wanted = named != 0;
 #pragma unroll
@@ -981,41 +1006,38 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                 guard.slack = fp.a_zero;
             }
             if (CONE == 4) {
-                // what bounds the task's rays together: a ball of origins and a cone of directions
+                // What bounds the rays of each pair of slots (128 consecutive rays of the queue) together:
+                // a ball of origins and a cone of directions (see filter_range).
                 guard.bounds = (const float*)(const void*)cone;
                 guard.slack = fp.a_zero;
-                float sx = 0.f, sy = 0.f, sz = 0.f, ox = 0.f, oy = 0.f, oz = 0.f;
-                v2f ux[RPL / 2], uy[RPL / 2], uz[RPL / 2];
 #pragma unroll
                 for (int k = 0; k < RPL / 2; k++) {
                     const v2f sc2 = {sqrtf(L.hz[k].x), sqrtf(L.hz[k].y)};                       // hz = 1 / |V|^2
-                    ux[k] = L.vx[k] * sc2; uy[k] = L.vy[k] * sc2; uz[k] = L.vz[k] * sc2;
-                    sx += ux[k].x + ux[k].y; sy += uy[k].x + uy[k].y; sz += uz[k].x + uz[k].y;
-                    ox += L.px[k].x + L.px[k].y; oy += L.py[k].x + L.py[k].y; oz += L.pz[k].x + L.pz[k].y;
-                }
-                for (int off = 32; off > 0; off >>= 1) {
-                    sx += __shfl_xor(sx, off); sy += __shfl_xor(sy, off); sz += __shfl_xor(sz, off);
-                    ox += __shfl_xor(ox, off); oy += __shfl_xor(oy, off); oz += __shfl_xor(oz, off);
-                }
-                const float inv = 1.0f / sqrtf(sx * sx + sy * sy + sz * sz);
-                const float ax = sx * inv, ay = sy * inv, az = sz * inv;
-                const float mx = ox * (1.0f / (RT_WAVE * RPL)), my = oy * (1.0f / (RT_WAVE * RPL)), mz = oz * (1.0f / (RT_WAVE * RPL));
-                float low = 1.0f, far2 = 0.f;
-#pragma unroll
-                for (int k = 0; k < RPL / 2; k++) {
-                    low = fminf(low, fminf(ax * ux[k].x + ay * uy[k].x + az * uz[k].x, ax * ux[k].y + ay * uy[k].y + az * uz[k].y));
+                    const v2f ux = L.vx[k] * sc2, uy = L.vy[k] * sc2, uz = L.vz[k] * sc2;
+                    float sx = ux.x + ux.y, sy = uy.x + uy.y, sz = uz.x + uz.y;
+                    float ox = L.px[k].x + L.px[k].y, oy = L.py[k].x + L.py[k].y, oz = L.pz[k].x + L.pz[k].y;
+                    for (int off = 32; off > 0; off >>= 1) {
+                        sx += __shfl_xor(sx, off); sy += __shfl_xor(sy, off); sz += __shfl_xor(sz, off);
+                        ox += __shfl_xor(ox, off); oy += __shfl_xor(oy, off); oz += __shfl_xor(oz, off);
+                    }
+                    const float inv = 1.0f / sqrtf(sx * sx + sy * sy + sz * sz);
+                    const float ax = sx * inv, ay = sy * inv, az = sz * inv;
+                    const float mx = ox * (1.0f / (2 * RT_WAVE)), my = oy * (1.0f / (2 * RT_WAVE)), mz = oz * (1.0f / (2 * RT_WAVE));
+                    float low = fminf(ax * ux.x + ay * uy.x + az * uz.x, ax * ux.y + ay * uy.y + az * uz.y);
                     const float ex = L.px[k].x - mx, ey = L.py[k].x - my, ez = L.pz[k].x - mz;
                     const float fx2 = L.px[k].y - mx, fy2 = L.py[k].y - my, fz2 = L.pz[k].y - mz;
-                    far2 = fmaxf(far2, fmaxf(ex * ex + ey * ey + ez * ez, fx2 * fx2 + fy2 * fy2 + fz2 * fz2));
+                    float far2 = fmaxf(ex * ex + ey * ey + ez * ez, fx2 * fx2 + fy2 * fy2 + fz2 * fz2);
+                    for (int off = 32; off > 0; off >>= 1) { low = fminf(low, __shfl_xor(low, off)); far2 = fmaxf(far2, __shfl_xor(far2, off)); }
+                    const float ro = sqrtf(far2) * (1.0f + 1e-5f) + 1e-6f * (fabsf(mx) + fabsf(my) + fabsf(mz));
+                    const float cb = low - 4e-6f;
+                    // (a NaN anywhere makes the axis NaN: fminf would drop it, the flags do not)
+                    const bool finite = (ax == ax) && (ay == ay) && (az == az) && (ro == ro) && (low == low);
+                    guard.qa[k][0] = uniform_f(ax); guard.qa[k][1] = uniform_f(ay); guard.qa[k][2] = uniform_f(az);
+                    guard.qa[k][3] = uniform_f(cb); guard.qa[k][4] = uniform_f(sqrtf(fmaxf(1.0f - cb * cb, 0.0f)) + 1e-6f);
+                    guard.qm[k][0] = uniform_f(mx); guard.qm[k][1] = uniform_f(my); guard.qm[k][2] = uniform_f(mz);
+                    guard.qm[k][3] = uniform_f(ro);
+                    guard.qon[k] = __builtin_amdgcn_readfirstlane((finite && cb > 0.0f) ? 1 : 0);
                 }
-                for (int off = 32; off > 0; off >>= 1) { low = fminf(low, __shfl_xor(low, off)); far2 = fmaxf(far2, __shfl_xor(far2, off)); }
-                const float ro = sqrtf(far2) * (1.0f + 1e-5f) + 1e-6f * (fabsf(mx) + fabsf(my) + fabsf(mz));
-                const float cb = low - 4e-6f;
-                const bool finite = (ax == ax) && (ay == ay) && (az == az) && (ro == ro);
-                guard.bx = uniform_f(ax); guard.by = uniform_f(ay); guard.bz = uniform_f(az);
-                guard.bcos = uniform_f(cb); guard.bsin = uniform_f(sqrtf(fmaxf(1.0f - cb * cb, 0.0f)) + 1e-6f);
-                guard.cx = uniform_f(mx); guard.cy = uniform_f(my); guard.cz = uniform_f(mz); guard.hx = uniform_f(ro);
-                guard.cull = __builtin_amdgcn_readfirstlane((finite && cb > 0.0f) ? 1 : 0);
             }
             if (CONE == 1 || CONE == 2) {
                 // what bounds the task's rays together (see filter_range)
