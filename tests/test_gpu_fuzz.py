@@ -205,3 +205,26 @@ def test_unusual_epsilons(family, eps, tmp_path):
         assert np.array_equal(img, want), (opts, int((img != want).any(axis=-1).sum()))
         for key in ("rays_reflect", "rays_shadow", "hits"):
             assert st[key] == sw[key], (key, opts)
+
+
+LARGE_SEEDS = range(11, 11 + int(os.environ.get("RT_FUZZ_LARGE_SEEDS", "2")))
+
+
+@pytest.mark.parametrize("family,seed", [(f, s) for f in FAMILIES for s in LARGE_SEEDS],
+                         ids=[f"{f}-{s}" for f in FAMILIES for s in LARGE_SEEDS])
+def test_bounding_tests_on_larger_frames(family, seed, tmp_path):
+    """The bounding tests work on bundles of hundreds of neighbouring rays; on frames large enough
+    that a bundle is a small part of the picture they must still change nothing: default against
+    RT_OPT_BOUNDING_TESTS = 0 (every pair takes the triangle test), frames and counts."""
+    path = os.path.join(str(tmp_path), "fuzz.scene")
+    with open(path, "w") as f:
+        f.write(random_scene(5000 * seed + FAMILIES.index(family), family))
+    sc = Scene.load(path, 640, 360, 4)
+    want, sw = render(sc, BOUNDING_TESTS=0)
+    for more in ({}, {"BOUNDING_TESTS": 2}, {"FILTER_FORM": 1}, {"FILTER_FORM": 2}):
+        if "FILTER_FORM" in more:
+            want, sw = render(sc, BOUNDING_TESTS=0, **more)
+        img, st = render(sc, **more)
+        assert np.array_equal(img, want), (more, int((img != want).any(axis=-1).sum()))
+        for key in ("rays_reflect", "rays_shadow", "hits", "in_plane_origin_hits"):
+            assert st[key] == sw[key], (key, more)
