@@ -314,7 +314,7 @@ struct Timed {
 
 // Nearest hit (MODE 0) or shadow (MODE 1) of one queue: filter, listed pairs, the rest.
 template <int MODE>
-int launch_trace(rt_ctx* c, TraceArgs A, hipStream_t st, bool camera_rays = false) {
+int launch_trace(rt_ctx* c, TraceArgs A, hipStream_t st, size_t max_rays, bool camera_rays = false) {
     const DevScene* dsc = c->d_scene.p;
     A.shared_origin_a = (MODE == 0 && camera_rays && c->shared_consts) ? c->eye_a.p : nullptr;
     A.shared_dir_rinv = (MODE == 1 && c->shared_consts && c->dir_rinv.n > 0) ? c->dir_rinv.p : nullptr;
@@ -330,7 +330,7 @@ int launch_trace(rt_ctx* c, TraceArgs A, hipStream_t st, bool camera_rays = fals
     A.task_counter = (unsigned int*)(c->pair_count[MODE].p + 1);
     A.pair_cap = (unsigned int)c->pair_cap[MODE]; A.counters = c->counters.p; A.scan_all = c->force_exact;
     HIP_TRY(hipMemsetAsync(c->pair_count[MODE].p, 0, 2 * sizeof(unsigned long long), st));
-    HIP_TRY(hipMemsetAsync(c->ray_flags[MODE].p, 0, c->ray_flags[MODE].n, st));
+    HIP_TRY(hipMemsetAsync(c->ray_flags[MODE].p, 0, std::min(c->ray_flags[MODE].n, max_rays), st));   // (no queue of the pass is longer)
     if (!c->force_exact && c->hs.n_regular > 0) {
         Timed t(c, st, (MODE == 0 && A.cone_camera && !c->use_bvh) ? 3 : MODE);
         if (c->use_bvh) {
@@ -465,7 +465,7 @@ int run_pass(rt_ctx* c, PassDesc pd, int nrows, hipStream_t st) {
         TraceArgs ta{};
         ta.rays = q[cur]; ta.n_items = c->counts.p + k; ta.keys = c->keys[cur].p;
         ta.occl_words = c->occl_words;
-        int rc = launch_trace<0>(c, ta, st, k == 0);
+        int rc = launch_trace<0>(c, ta, st, (size_t)n_pix, k == 0);
         if (rc) return rc;
 
         if (overlap && k >= 2) HIP_TRY(hipStreamWaitEvent(st, c->ev_phong[k - 2], 0));
@@ -486,7 +486,7 @@ int run_pass(rt_ctx* c, PassDesc pd, int nrows, hipStream_t st) {
             TraceArgs sa{};
             sa.rays = q[nxt]; sa.n_items = c->counts.p + k + 1; sa.source_obj = lvl.obj;
             sa.occluded = occl; sa.occl_words = c->occl_words;
-            rc = launch_trace<1>(c, sa, sb);
+            rc = launch_trace<1>(c, sa, sb, (size_t)n_pix * (size_t)std::max(1, c->hs.n_lights));
             if (rc) return rc;
         }
 
@@ -1275,7 +1275,7 @@ int rt_primary_hits(rt_ctx* c, int y0, int rows, uint64_t* keys, size_t count) {
         HIP_TRY(hipGetLastError());
         TraceArgs ta{};
         ta.rays = q; ta.n_items = c->counts.p; ta.keys = c->keys[0].p; ta.occl_words = c->occl_words;
-        rc = launch_trace<0>(c, ta, st, true);
+        rc = launch_trace<0>(c, ta, st, (size_t)n_pix, true);
         if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipMemcpy(keys + (size_t)q0 * W, c->keys[0].p, (size_t)n_pix * sizeof(uint64_t), hipMemcpyDeviceToHost));

@@ -819,6 +819,13 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
     if (n_ray_blocks < 8u * n_waves) {
         split = (int)((8u * n_waves + n_ray_blocks - 1) / n_ray_blocks);
         if (split > max_split) split = max_split;
+        // (a launch that cannot give every wave a task even so -- a few thousand rays, the deep
+        // reflection levels -- lasts as long as its longest task: parts down to 128 triangles)
+        if (CONE && (unsigned int)split * n_ray_blocks < n_waves) {
+            const int finest = (NR + 127) / 128;
+            split = (int)((n_waves + n_ray_blocks - 1) / n_ray_blocks);
+            if (split > finest) split = finest;
+        }
     }
     const unsigned int n_tasks = n_ray_blocks * (unsigned int)split;
     const int n_groups = sc->n_groups;
@@ -1349,19 +1356,24 @@ k_hit_offsets(const unsigned long long* __restrict__ keys, const uint32_t* __res
         if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
         __syncthreads();
     }
+    // Only blocks that own rays take part (a short queue must not cost a full grid's worth of
+    // atomics on one counter); an empty queue is block 0's to report.
+    const unsigned int active = (n + per - 1) / per;
+    if (n == 0) { if (blockIdx.x == 0 && threadIdx.x == 0) *n_hits = 0u; return; }
+    if (blockIdx.x >= active) return;
     if (threadIdx.x == 0) {
         __hip_atomic_store(&offsets[blockIdx.x], part[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence();
-        last_block = atomicAdd(&offsets[G], 1u) == G - 1u;
+        last_block = atomicAdd(&offsets[G], 1u) == active - 1u;
     }
     __syncthreads();
     if (!last_block) return;
     __threadfence();
-    // exclusive scan of the G counts by this block: a run of consecutive entries per thread
-    const unsigned int run = (G + RT_BLOCK - 1) / RT_BLOCK;
+    // exclusive scan of the counts by this block: a run of consecutive entries per thread
+    const unsigned int run = (active + RT_BLOCK - 1) / RT_BLOCK;
     const unsigned int first = threadIdx.x * run;
     unsigned int sum = 0;
-    for (unsigned int k = first; k < first + run && k < G; k++)
+    for (unsigned int k = first; k < first + run && k < active; k++)
         sum += __hip_atomic_load(&offsets[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     part[threadIdx.x] = sum;
@@ -1373,7 +1385,7 @@ k_hit_offsets(const unsigned long long* __restrict__ keys, const uint32_t* __res
         __syncthreads();
     }
     unsigned int at = part[threadIdx.x] - sum;
-    for (unsigned int k = first; k < first + run && k < G; k++) {
+    for (unsigned int k = first; k < first + run && k < active; k++) {
         const unsigned int cnt = __hip_atomic_load(&offsets[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         offsets[k] = at;
         at += cnt;
