@@ -816,8 +816,12 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
 #endif
     int max_split = CONE ? (NR + RT_MIN_PART_BOUNDED - 1) / RT_MIN_PART_BOUNDED : (NR + 127) / 128;
     int split = 1;
-    if (n_ray_blocks < 8u * n_waves) {
-        split = (int)((8u * n_waves + n_ray_blocks - 1) / n_ray_blocks);
+#ifndef RT_TASKS_PER_WAVE_BOUNDED
+#define RT_TASKS_PER_WAVE_BOUNDED 3
+#endif
+    const unsigned int per_wave = CONE ? RT_TASKS_PER_WAVE_BOUNDED : 8u;       // tasks per wave to aim for
+    if (n_ray_blocks < per_wave * n_waves) {
+        split = (int)((per_wave * n_waves + n_ray_blocks - 1) / n_ray_blocks);
         if (split > max_split) split = max_split;
         // (a launch that cannot give every wave a task even so -- a few thousand rays, the deep
         // reflection levels -- lasts as long as its longest task: parts down to 128 triangles)
