@@ -1,9 +1,9 @@
 // The trace loop as a wavefront pipeline.  One "level" is one generation of
 // rays (level 0 = camera rays, level k = k-th reflection).  Per level:
 //   nearest hit  of every ray in the level's queue  (k_filter<0> -> k_exact_pairs<0>, k_brute<0>)
-//   k_hit        compacts the rays that hit something (ballot + one atomic per
-//                wave), computes hit point, normal and reflection, and writes
-//                the next level's ray queue
+//   k_hit        compacts the rays that hit something, in the order of the rays
+//                (k_hit_offsets: hits per block -> offsets), computes hit point,
+//                normal and reflection, and writes the next level's ray queue
 //   shadow rays  one per (hit, light)               (k_filter<1> -> k_exact_pairs<1>, k_brute<1>)
 //   k_phong      Phong sum over the unshadowed lights
 // and after the last level k_fold walks the levels deepest-first to evaluate
@@ -12,7 +12,8 @@
 // is read back by the host between kernels.
 //
 // The trace kernels scan every primitive for every ray.  Regular triangles
-// go through an FP32 filter (16 floats per triangle, wave-uniform, so the
+// go through bounding tests (can a bundle of neighbouring rays, can a lane's rays
+// reach the triangle's bounding sphere at all: filter_range) and an FP32 filter (16 floats per triangle, wave-uniform, so the
 // compiler fetches them with scalar loads and they never occupy vector
 // registers); pairs the filter cannot rule out are staged per lane in LDS, listed
 // in global memory and re-evaluated in the reference's mixed double/float
@@ -431,13 +432,20 @@ typedef __attribute__((address_space(4))) const v4u cv4u;
 // their axes is at most the sum of their half-angles, discs when their centres are closer than
 // the sum of their radii -- and a ballot turns the answers into a scalar mask: batches of four
 // triangles none of which the bundle can reach (and the plane guard does not name) cost a few
-// scalar instructions.
+// scalar instructions, a group of 64 out of reach is skipped as a whole.  The rays of one scanline
+// also fan out in (nearly) one plane through the shared point; a sphere whose axis leaves that
+// plane by more than the two angles together is out of reach as well.
 //
 // PRE = 4: rays with nothing in common (reflection rays).  Squared distance of the sphere's
 // centre from the ray's line, |C - P|^2 - ((C - P).V)^2 / |V|^2 <= rho^2, expanded so that the
 // per-ray parts (P.V, |P|^2, 1 / |V|^2) are computed once per task: nine multiply-adds per ray,
 // no reciprocal; the rounding of the expanded form is part of the radius.  The in-plane-origin
 // case is asked per pair here: a = d0 - n.P from a compact copy of the planes (three more).
+// One level up: a bundle per pair of ray slots (128 consecutive rays of the queue) -- a ball of
+// origins (m, ro) and a cone of directions.  A line through P stays within |P - m| of the parallel
+// line through m, so the bundle reaches the sphere (C, rho) only if a line through m inside the
+// cone of directions reaches (C, rho + ro); the in-plane-origin case needs the plane to pass
+// through the ball.  A pair whose bundle reaches none of a batch's triangles sits the batch out.
 struct PlaneGuard {
     const float* planes;                 // PRE 4: (n, d0) per triangle, 4 floats each
     const float* records;                // the filter records as plain memory (16 floats per triangle)
