@@ -1264,6 +1264,7 @@ int rt_primary_hits(rt_ctx* c, int y0, int rows, uint64_t* keys, size_t count) {
     const int rows_per_pass = (int)(c->cap / W);
     hipStream_t st = nullptr;
     const DevScene* dsc = c->d_scene.p;
+    std::vector<uint64_t> queued;
     for (int q0 = 0; q0 < rows; q0 += rows_per_pass) {
         const int nrows = std::min(rows_per_pass, rows - q0);
         const int n_pix = nrows * W;
@@ -1278,7 +1279,14 @@ int rt_primary_hits(rt_ctx* c, int y0, int rows, uint64_t* keys, size_t count) {
         rc = launch_trace<0>(c, ta, st, (size_t)n_pix, true);
         if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(st));
-        HIP_TRY(hipMemcpy(keys + (size_t)q0 * W, c->keys[0].p, (size_t)n_pix * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        // the queue is in tile order (queue_pixel); the caller's array is in scanline order
+        queued.resize((size_t)n_pix);
+        HIP_TRY(hipMemcpy(queued.data(), c->keys[0].p, (size_t)n_pix * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        for (int p = 0; p < n_pix; p++) {
+            int row, x;
+            queue_pixel(p, W, nrows, &row, &x);
+            keys[(size_t)(q0 + row) * W + x] = queued[(size_t)p];
+        }
     }
     return 0;
 }

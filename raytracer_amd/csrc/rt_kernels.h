@@ -73,13 +73,38 @@ struct DevCounters {
 // Camera::generateRay (raytracer.cpp:441-447) for the pixels of a pass, plus the
 // black background of pixels whose ray hits nothing (raytracer.cpp:546).
 // ---------------------------------------------------------------------------
+//
+// Queue order: which pixel a queue index stands for is free (every ray carries its pixel), and
+// the scans bound the rays of a wave together, so neighbours in the queue should be neighbours
+// on the screen in both directions.  The pass's rows are cut into bands of RT_TILE rows, a band
+// into tiles of RT_TILE x RT_TILE pixels, a tile into four 8 x 8 blocks (64 consecutive queue
+// indices = one ray slot of a wave).  What does not fill a tile (the band's last columns, the
+// pass's last rows) stays in scanline order.
+// ---------------------------------------------------------------------------
+#ifndef RT_TILE
+#define RT_TILE 16
+#endif
+__host__ __device__ __forceinline__ void queue_pixel(int p, int W, int rows, int* row, int* x) {
+    const int T = RT_TILE, band = T * W, bands = rows / T;
+    if (p >= bands * band) { const int r = p - bands * band; *row = bands * T + r / W; *x = r % W; return; }
+    const int b = p / band, i = p % band, wide = (W / T) * T * T;
+    if (i >= wide) { const int w = W % T, j = i - wide; *row = b * T + j / w; *x = (W / T) * T + j % w; return; }
+    const int t = i / (T * T), j = i % (T * T), block = j >> 6, k = j & 63;
+    const int bx = (block & 1) | ((block >> 1) & 2) | ((block >> 2) & 4);       // blocks in Z order
+    const int by = ((block >> 1) & 1) | ((block >> 2) & 2) | ((block >> 3) & 4);
+    *row = b * T + by * 8 + (k >> 3);
+    *x = t * T + bx * 8 + (k & 7);
+}
+
 __global__ void __launch_bounds__(RT_BLOCK)
 k_primary(const DevScene* __restrict__ sc, PassDesc pd, int n_pix, RayQueue q,
           unsigned long long* __restrict__ keys, int32_t* __restrict__ pixel_of_ray,
           uint32_t* __restrict__ frame, uint32_t* __restrict__ counts) {
     int W = sc->width, H = sc->height;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n_pix; p += gridDim.x * blockDim.x) {
-        int qrow = pd.q0 + p / W, x = p % W;
+        int row, x;
+        queue_pixel(p, W, n_pix / W, &row, &x);
+        int qrow = pd.q0 + row;
         int y = pd.y_start + (qrow / pd.tile_rows) * pd.stride_rows + qrow % pd.tile_rows;
         float u = (float)x / (float)W;
         float v = (float)y / (float)H;

@@ -40,7 +40,9 @@ CONFIGS = [("static", {"FILTER_FORM": 1}), ("per-test", {"FILTER_FORM": 2}), ("e
 
 @pytest.mark.parametrize("name,w,h", [("teapot", 96, 54), ("mixed_xf", 80, 60), ("campanile_teddy", 64, 36),
                                      ("scene1", 64, 64), ("input-09", 64, 64), ("input-07", 64, 64),
-                                     ("synthetic_small", 80, 45), ("normals", 64, 48)])
+                                     ("synthetic_small", 80, 45), ("normals", 64, 48),
+                                     # sizes that leave partial tiles in the queue's tile order
+                                     ("teapot", 75, 41), ("scene1", 37, 16), ("teapot", 15, 33), ("teapot", 131, 7)])
 def test_nearest_hit_index_and_distance_bits(name, w, h, oracle):
     from raytracer_amd.render import Renderer
     sc = Scene.load(scene_file(name), w, h, 1)
