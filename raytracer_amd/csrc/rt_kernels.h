@@ -34,6 +34,9 @@
 #ifndef RT_RPL_SHARED
 #define RT_RPL_SHARED 8         // ... in its instances for rays that share a point or a direction
 #endif
+#ifndef RT_GROUPS_AHEAD
+#define RT_GROUPS_AHEAD 4       // groups of 64 triangles whose bounding records a wave requests together
+#endif
 #ifndef RT_RPL_ANY
 #define RT_RPL_ANY 4            // ... in its instance with a bounding test for rays with nothing in common (256 rays per
                                 // task ask for fewer triangles than 512; the scans of camera and shadow rays lose by it)
@@ -500,7 +503,8 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                                              const FilterLane<RPL>& L, const FilterQuery fp, int abeg, int aend,
                                              unsigned short* my_cand, unsigned int ray0, unsigned int n_rays, int lane) {
     constexpr int SLOT_SHIFT = RT_SLOT_SHIFT(RPL);
-    constexpr int CHUNK = 1 << SLOT_SHIFT;
+    // (with a bounding test: at most 64 groups of 64 triangles, one lane per group's masks)
+    constexpr int CHUNK = (PRE && SLOT_SHIFT > 12) ? 4096 : (1 << SLOT_SHIFT);
     v2f pu[RPL / 2], pv[RPL / 2], vu[RPL / 2], vv[RPL / 2];
 #pragma unroll
     for (int q = 0; q < RPL / 2; q++) {
@@ -559,129 +563,196 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
         }
     };
     v16f cones_cur = {}, cones_nxt = {}, planes_cur = {}, planes_nxt = {};
-    bool chain_broken = true;                 // cones_nxt / planes_nxt do not hold the batch about to be evaluated
+    int nxt_index = -1;                       // the batch whose records cones_nxt / planes_nxt hold (-1: none)
     unsigned long long guard_mask = 0, reach_mask = ~0ull;
     unsigned long long pair_mask[RPL / 2];    // PRE 4: per pair of ray slots, the triangles of the group its bundle can reach
 #pragma unroll
     for (int q = 0; q < RPL / 2; q++) pair_mask[q] = ~0ull;
     int guard_base = 0;
-    // Per group of 64 triangles every lane looks at one triangle (bounding record, plane); the
-    // records of the next group are requested while this one is scanned.
-    float4 grp_rec = make_float4(0.f, 0.f, 0.f, 0.f), grp_pl = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto request_group = [&](const int jg) {
-        const int j = jg + lane;
-        if (j < aend) {
-            grp_rec = *(const float4*)(guard.bounds + 4 * (size_t)j);
-            if (PRE == 4) grp_pl = *(const float4*)(guard.planes + 4 * (size_t)j);
-            if (PRE == 2 || PRE == 3) grp_pl = *(const float4*)(guard.records + 16 * (size_t)j);
+    // Per group of 64 triangles every lane looks at one triangle (bounding record, plane) and the
+    // answers become lane masks.  A chunk's groups are judged before its triangles are scanned,
+    // RT_GROUPS_AHEAD groups per round with all their records requested together (one memory
+    // latency per round, not per group); group g's masks wait in lane g of a register pair, and
+    // one bit per group says whether any triangle of it is wanted at all.
+    constexpr int NM = (PRE == 4) ? RPL / 2 : 2;
+    int kept_lo[NM], kept_hi[NM];
+#pragma unroll
+    for (int k = 0; k < NM; k++) { kept_lo[k] = 0; kept_hi[k] = 0; }
+    unsigned long long live_groups = 0ull;
+    auto group_masks = [&](const int j, const int cend, const float4 rec, const float4 pl, unsigned long long* out) {
+        if (PRE == 4) {
+            // A line through P with direction V stays within |P - m| of the parallel line through m, so
+            // a bundle (origins within ro of m, directions within a cone) reaches the sphere (C, rho) only
+            // if a line through m inside that cone reaches (C, rho + ro).  In-plane-origin case: the
+            // triangle's plane passes through the ball of origins.
+            // rec = centre, rho^2 - |C|^2; pl = (n, d0)
+            const float rho = sqrtf(fmaxf(rec.w + rec.x * rec.x + rec.y * rec.y + rec.z * rec.z, 0.0f));
+#pragma unroll
+            for (int q = 0; q < RPL / 2; q++) {
+                bool live = j < cend;
+                if (guard.qon[q] && j < cend) {
+                    const float dx = rec.x - guard.qm[q][0], dy = rec.y - guard.qm[q][1], dz = rec.z - guard.qm[q][2];
+                    const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+                    const float sn = (rho + guard.qm[q][3]) * (1.0f + 1e-5f) / dist;
+                    const float along = fabsf(dx * guard.qa[q][0] + dy * guard.qa[q][1] + dz * guard.qa[q][2]) / dist;
+                    const float cs = sqrtf(fmaxf(1.0f - sn * sn, 0.0f));
+                    const bool in_reach = !(sn < 0.999f) | !(along < cs * guard.qa[q][3] - sn * guard.qa[q][4] - 1e-5f);
+                    const bool is_named = !(fabsf(pl.x * guard.qm[q][0] + pl.y * guard.qm[q][1] + pl.z * guard.qm[q][2] - pl.w) >
+                                            guard.qm[q][3] + 2.0f * guard.slack);
+                    live = in_reach | is_named;
+                }
+                out[q] = __ballot(live);
+            }
+        } else {
+            bool is_named = false, in_reach = j < cend;
+            if ((PRE == 2 || PRE == 3) && j < cend) {
+                // pl = (n, d0)
+                const float across = pl.x * guard.lx + pl.y * guard.ly + pl.z * guard.lz;
+                const float off = guard.point ? fabsf(pl.w - across) : fabsf(across);
+                const float centre = fabsf(pl.x * guard.cx + pl.y * guard.cy + pl.z * guard.cz - pl.w);
+                const float reach = fabsf(pl.x) * guard.hx + fabsf(pl.y) * guard.hy + fabsf(pl.z) * guard.hz + guard.slack;
+                is_named = !(off > guard.limit) && !(centre > reach);
+            }
+            if (guard.cull && j < cend) {
+                if (PRE == 3) {
+                    const float cu = -0.5f * rec.x, cv = -0.5f * rec.y;
+                    const float rho = sqrtf(fmaxf(rec.z + cu * cu + cv * cv, 0.0f));      // (radius^2 = k + c.c; inf stays inf)
+                    const float du = cu - guard.bx, dv = cv - guard.by, sum = rho + guard.bcos;
+                    in_reach = !(du * du + dv * dv > sum * sum * (1.0f + 1e-5f));
+                } else {
+                    float along = rec.x * guard.bx + rec.y * guard.by + rec.z * guard.bz;
+                    if (PRE == 2) along = fabsf(along);
+                    const float ct = rec.w, st = sqrtf(fmaxf(1.0f - ct * ct, 0.0f));
+                    in_reach = (ct < -1.0f) | !(along < ct * guard.bcos - st * guard.bsin - 1e-5f);
+                    // ... and the sphere's axis may leave the fan's plane by at most the two angles together
+                    const float aside = fabsf(rec.x * guard.fx + rec.y * guard.fy + rec.z * guard.fz);
+                    const bool in_fan = (ct < -1.0f) | !(ct * guard.fcos - st * guard.fsin > 0.0f) |
+                                        !(aside > st * guard.fcos + ct * guard.fsin + 1e-5f);
+                    in_reach &= in_fan;
+                }
+            }
+            out[1] = __ballot(is_named);
+            out[0] = __ballot(in_reach | is_named);
         }
     };
-    if (PRE) request_group(abeg);
     for (cbeg = abeg; cbeg < aend; cbeg += CHUNK) {
         const int cend = min(cbeg + CHUNK, aend);
         n_cand = 0;
+        if (PRE) {
+            live_groups = 0ull;
+            const int n_grp = (cend - cbeg + 63) >> 6;
+            for (int g0 = 0; g0 < n_grp; g0 += RT_GROUPS_AHEAD) {
+                float4 rec[RT_GROUPS_AHEAD], pl[RT_GROUPS_AHEAD];
+#pragma unroll
+                for (int u = 0; u < RT_GROUPS_AHEAD; u++) {
+                    const int j = cbeg + (g0 + u) * 64 + lane;
+                    rec[u] = make_float4(0.f, 0.f, 0.f, 0.f); pl[u] = rec[u];
+                    if (j < cend) {
+                        rec[u] = *(const float4*)(guard.bounds + 4 * (size_t)j);
+                        if (PRE == 4) pl[u] = *(const float4*)(guard.planes + 4 * (size_t)j);
+                        if (PRE == 2 || PRE == 3) pl[u] = *(const float4*)(guard.records + 16 * (size_t)j);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < RT_GROUPS_AHEAD; u++) {
+                    if (g0 + u < n_grp) {
+                        unsigned long long out[NM];
+                        group_masks(cbeg + (g0 + u) * 64 + lane, cend, rec[u], pl[u], out);
+                        unsigned long long any = out[0];
+                        if (PRE == 4) {
+#pragma unroll
+                            for (int k = 1; k < NM; k++) any |= out[k];
+                        }
+                        if (any != 0ull) {
+                            live_groups |= 1ull << (g0 + u);
+#pragma unroll
+                            for (int k = 0; k < NM; k++) {
+                                kept_lo[k] = (lane == g0 + u) ? (int)(unsigned int)out[k] : kept_lo[k];
+                                kept_hi[k] = (lane == g0 + u) ? (int)(unsigned int)(out[k] >> 32) : kept_hi[k];
+                            }
+                        }
+                    }
+                }
+            }
+        }
         for (int j0 = cbeg; j0 < cend; j0 += RT_BATCH) {
             int jn = min(j0 + RT_BATCH, cend);
+            int j_next = j0 + RT_BATCH;               // where the scan goes on after this batch
             if (PRE) {
-                // The cone records of a batch (4 x 16 bytes) come in one scalar load, requested a
-                // batch ahead; the four tests run back to back (independent chains), one branch
-                // per batch asks whether any lane wants any of the four triangles, and only then
-                // is a triangle record fetched (the scalar cache cannot feed 64-byte records at
+                // Only batches with a wanted triangle are visited (the masks say which).  The cone
+                // records of a batch (4 x 16 bytes) come in one scalar load, requested while the wanted
+                // batch before it is evaluated; the four tests run back to back (independent chains),
+                // one branch per batch asks whether any lane wants any of the four triangles, and only
+                // then is a triangle record fetched (the scalar cache cannot feed 64-byte records at
                 // the pace of the cone test).  The arrays are readable a batch past their end.
                 // (Scalar loads return out of order, so waiting for one waits for all: the only load
-                // in flight while a batch is evaluated must be the next batch's.  The first batch's
-                // records are requested before the loops, batches follow each other without gaps.)
-                // A batch out of reach of the task's bundle does not touch that chain at all, a group
-                // of 64 out of reach is skipped as a whole; the first batch after a gap requests its own
-                // records and waits for them.
+                // in flight while a batch is evaluated must be the next wanted batch's.  The first
+                // wanted batch of a chunk requests its own records and waits for them.)
                 // (one comparison per triangle, kept as a lane mask; the four are merged on the scalar
                 // unit and turned into per-lane bits only inside the branch)
                 bool wants[RT_BATCH];
                 unsigned int named = 0;
-                if (PRE == 4 && ((j0 - cbeg) & 63) == 0) {
-                    // A line through P with direction V stays within |P - m| of the parallel line through m, so
-                    // a bundle (origins within ro of m, directions within a cone) reaches the sphere (C, rho) only
-                    // if a line through m inside that cone reaches (C, rho + ro).  In-plane-origin case: the
-                    // triangle's plane passes through the ball of origins.
-                    const int j = j0 + lane;
-                    const float4 rec = grp_rec;                                                   // centre, rho^2 - |C|^2
-                    const float4 pl = grp_pl;                                                     // (n, d0)
-                    const float rho = sqrtf(fmaxf(rec.w + rec.x * rec.x + rec.y * rec.y + rec.z * rec.z, 0.0f));
-                    reach_mask = 0ull;
+                if (((j0 - cbeg) & 63) == 0) {
+                    int g = (j0 - cbeg) >> 6;
+                    const unsigned long long rest = live_groups >> g;
+                    if (rest == 0ull) {
+                        // nothing wanted up to the end of the chunk
+                        reach_mask = 0ull; guard_mask = 0ull;
 #pragma unroll
-                    for (int q = 0; q < RPL / 2; q++) {
-                        bool live = true;
-                        if (guard.qon[q] && j < cend) {
-                            const float dx = rec.x - guard.qm[q][0], dy = rec.y - guard.qm[q][1], dz = rec.z - guard.qm[q][2];
-                            const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
-                            const float sn = (rho + guard.qm[q][3]) * (1.0f + 1e-5f) / dist;
-                            const float along = fabsf(dx * guard.qa[q][0] + dy * guard.qa[q][1] + dz * guard.qa[q][2]) / dist;
-                            const float cs = sqrtf(fmaxf(1.0f - sn * sn, 0.0f));
-                            const bool in_reach = !(sn < 0.999f) | !(along < cs * guard.qa[q][3] - sn * guard.qa[q][4] - 1e-5f);
-                            const bool is_named = !(fabsf(pl.x * guard.qm[q][0] + pl.y * guard.qm[q][1] + pl.z * guard.qm[q][2] - pl.w) >
-                                                    guard.qm[q][3] + 2.0f * guard.slack);
-                            live = in_reach | is_named;
+                        for (int q = 0; q < RPL / 2; q++) pair_mask[q] = 0ull;
+                        j0 = cend - RT_BATCH;
+                        jn = cend;
+                        j_next = cend;
+                        guard_base = j0;
+                    } else {
+                        const int skip = __builtin_ctzll(rest);
+                        g += skip;
+                        j0 += 64 * skip;
+                        unsigned long long got[NM];
+#pragma unroll
+                        for (int k = 0; k < NM; k++) {
+                            got[k] = (unsigned long long)(unsigned int)__builtin_amdgcn_readlane(kept_lo[k], g) |
+                                     ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane(kept_hi[k], g) << 32);
                         }
-                        pair_mask[q] = __ballot(live);
-                        reach_mask |= pair_mask[q];
-                    }
-                    guard_base = j0;
-                    request_group(j0 + 64);
-                }
-                if (PRE != 4 && ((j0 - cbeg) & 63) == 0) {
-                    const int j = j0 + lane;
-                    bool is_named = false, in_reach = true;
-                    if ((PRE == 2 || PRE == 3) && j < cend) {
-                        const float4 pl = grp_pl;                                                // (n, d0)
-                        const float across = pl.x * guard.lx + pl.y * guard.ly + pl.z * guard.lz;
-                        const float off = guard.point ? fabsf(pl.w - across) : fabsf(across);
-                        const float centre = fabsf(pl.x * guard.cx + pl.y * guard.cy + pl.z * guard.cz - pl.w);
-                        const float reach = fabsf(pl.x) * guard.hx + fabsf(pl.y) * guard.hy + fabsf(pl.z) * guard.hz + guard.slack;
-                        is_named = !(off > guard.limit) && !(centre > reach);
-                    }
-                    if (guard.cull && j < cend) {
-                        const float4 rec = grp_rec;
-                        if (PRE == 3) {
-                            const float cu = -0.5f * rec.x, cv = -0.5f * rec.y;
-                            const float rho = sqrtf(fmaxf(rec.z + cu * cu + cv * cv, 0.0f));      // (radius^2 = k + c.c; inf stays inf)
-                            const float du = cu - guard.bx, dv = cv - guard.by, sum = rho + guard.bcos;
-                            in_reach = !(du * du + dv * dv > sum * sum * (1.0f + 1e-5f));
+                        if (PRE == 4) {
+                            reach_mask = 0ull;
+#pragma unroll
+                            for (int q = 0; q < RPL / 2; q++) { pair_mask[q] = got[q]; reach_mask |= got[q]; }
                         } else {
-                            float along = rec.x * guard.bx + rec.y * guard.by + rec.z * guard.bz;
-                            if (PRE == 2) along = fabsf(along);
-                            const float ct = rec.w, st = sqrtf(fmaxf(1.0f - ct * ct, 0.0f));
-                            in_reach = (ct < -1.0f) | !(along < ct * guard.bcos - st * guard.bsin - 1e-5f);
-                            // ... and the sphere's axis may leave the fan's plane by at most the two angles together
-                            const float aside = fabsf(rec.x * guard.fx + rec.y * guard.fy + rec.z * guard.fz);
-                            const bool in_fan = (ct < -1.0f) | !(ct * guard.fcos - st * guard.fsin > 0.0f) |
-                                                !(aside > st * guard.fcos + ct * guard.fsin + 1e-5f);
-                            in_reach &= in_fan;
+                            reach_mask = got[0];
+                            guard_mask = got[1];
                         }
+                        guard_base = j0;
+                        // on to the group's first wanted batch (a live group has one)
+                        j0 += __builtin_ctzll(reach_mask) & ~(RT_BATCH - 1);
+                        jn = min(j0 + RT_BATCH, cend);
+                        j_next = j0 + RT_BATCH;
                     }
-                    guard_mask = __ballot(is_named);
-                    reach_mask = __ballot(in_reach | is_named);
-                    guard_base = j0;
-                    request_group(j0 + 64);
-                }
-                if (((j0 - cbeg) & 63) == 0 && reach_mask == 0ull) {
-                    // the whole group is out of reach: on to the next one (or to the end of the chunk)
-                    j0 = min(j0 + 64, cend) - RT_BATCH;
-                    jn = j0 + RT_BATCH;
-                    chain_broken = true;
                 }
                 const bool out_of_reach = ((reach_mask >> (j0 - guard_base)) & ((1ull << RT_BATCH) - 1ull)) == 0ull;
-                if (out_of_reach) chain_broken = true;
                 if (!out_of_reach) {
-                if (chain_broken) {
+                if (nxt_index != j0) {
                     cones_nxt = *(const cv16u*)((const cfloat*)cone + 4 * (size_t)j0);
                     if (PRE == 4) planes_nxt = *(const cv16u*)((const cfloat*)guard.planes + 4 * (size_t)j0);
-                    chain_broken = false;
                 }
                 cones_cur = cones_nxt;
-                cones_nxt = *(const cv16u*)((const cfloat*)cone + 4 * (size_t)(j0 + RT_BATCH));
-                if (PRE == 4) {
-                    planes_cur = planes_nxt;
-                    planes_nxt = *(const cv16u*)((const cfloat*)guard.planes + 4 * (size_t)(j0 + RT_BATCH));
+                if (PRE == 4) planes_cur = planes_nxt;
+                // the next wanted batch of this group (the first one of another group fetches its own records)
+                {
+                    const int off = j0 - guard_base + RT_BATCH;
+                    const unsigned long long ahead = (off < 64) ? (reach_mask >> off) : 0ull;
+                    int jl = -1;
+                    if (ahead != 0ull) {
+                        jl = j0 + RT_BATCH + (__builtin_ctzll(ahead) & ~(RT_BATCH - 1));
+                        j_next = jl;
+                    } else {
+                        j_next = min(guard_base + 64, cend);
+                    }
+                    if (jl >= 0) {
+                        cones_nxt = *(const cv16u*)((const cfloat*)cone + 4 * (size_t)jl);
+                        if (PRE == 4) planes_nxt = *(const cv16u*)((const cfloat*)guard.planes + 4 * (size_t)jl);
+                    }
+                    nxt_index = jl;
                 }
                 if (PRE == 2 || PRE == 3) named = (unsigned int)(guard_mask >> (j0 - guard_base)) & ((1u << RT_BATCH) - 1u);
 #pragma unroll
@@ -802,11 +873,12 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
             }
             // Flush when some lane could overflow its staging slots during the next batch,
             // and at the end of the chunk (entries are relative to the chunk base).
-            const bool last = jn >= cend;
+            const bool last = j_next >= cend;
             if (__any(n_cand > RT_CAND_CAP - RT_BATCH * RPL) || (last && __any(n_cand > 0))) {
                 flush_candidates<RPL>(A, my_cand, n_cand, cbeg, ray0, n_rays, lane);
                 n_cand = 0;
             }
+            j0 = j_next - RT_BATCH;
         }
     }
 }
