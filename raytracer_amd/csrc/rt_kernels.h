@@ -454,15 +454,15 @@ typedef __attribute__((address_space(4))) const v4u cv4u;
 // <= b_hi.  Once per 64 triangles every lane evaluates that for one of them and a ballot turns
 // the answers into a scalar mask; triangles it names take the triangle test whatever the cone says.
 //
-// PRE = 1, 2, 3, one level up: the task's 512 rays are neighbours on the film, so one cone
-// (one disc) bounds them all, and most triangles are out of reach of the whole bundle.  Once
-// per 64 triangles every lane asks that for one triangle -- cones meet when the angle between
-// their axes is at most the sum of their half-angles, discs when their centres are closer than
-// the sum of their radii -- and a ballot turns the answers into a scalar mask: batches of four
-// triangles none of which the bundle can reach (and the plane guard does not name) cost a few
-// scalar instructions, a group of 64 out of reach is skipped as a whole.  The rays of one scanline
-// also fan out in (nearly) one plane through the shared point; a sphere whose axis leaves that
-// plane by more than the two angles together is out of reach as well.
+// PRE = 1, 2, 3, one level up: the task's 512 rays are neighbours on the film (a patch of
+// 32 x 16 pixels in the queue's tile order, see queue_pixel), so one cone (one disc) bounds them
+// all, and most triangles are out of reach of the whole bundle.  Once per 64 triangles every lane
+// asks that for one triangle -- cones meet when the angle between their axes is at most the sum
+// of their half-angles, discs when their centres are closer than the sum of their radii -- and a
+// ballot turns the answers into a scalar mask; the scan then visits only batches of four with a
+// triangle the bundle can reach or the plane guard names.  Where a task's rays are a strip (the
+// last rows of a pass) they also fan out in (nearly) one plane through the shared point; a sphere
+// whose axis leaves that plane by more than the two angles together is out of reach as well.
 //
 // PRE = 4: rays with nothing in common (reflection rays).  Squared distance of the sphere's
 // centre from the ray's line, |C - P|^2 - ((C - P).V)^2 / |V|^2 <= rho^2, expanded so that the
@@ -488,7 +488,7 @@ struct PlaneGuard {
     const float* bounds;                 // the table `cone` points to, as plain memory
     float bx, by, bz, bcos, bsin;
     int cull;
-    // PRE 1, 2: neighbours on one scanline fan out in (nearly) one plane through the shared point: unit
+    // PRE 1, 2: rays of one scanline fan out in (nearly) one plane through the shared point: unit
     // normal of that plane (zero: no such plane), sine and cosine of the largest angle a ray makes with it
     float fx, fy, fz, fsin, fcos;
     // PRE 4: one bundle per pair of ray slots (128 consecutive rays of the queue): ball of origins (centre,
