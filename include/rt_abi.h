@@ -177,6 +177,15 @@ int rt_download(rt_ctx* ctx, uint8_t* rgba, size_t bytes);
  * rows of the frame black. */
 int rt_primary_hits(rt_ctx* ctx, int y0, int rows, uint64_t* keys, size_t count);
 
+/* Test hook, host arithmetic only (needs no GPU and no ctx): the pixel that index p of the ray
+ * queue of a pass stands for.  A pass of `rows` film rows of `width` pixels numbers its camera rays
+ * in tile order (16 x 16 pixel tiles of four 8 x 8 blocks; what does not fill a tile in scanline
+ * order), so that rays that are neighbours in the queue are neighbours on the film in both
+ * directions; the reference's loops (raytracer.cpp:502-511) visit one scanline after the other and
+ * nothing in them depends on that order.  *row in [0, rows) counts from the pass's first row, *x
+ * in [0, width).  Returns RT_ERR_ARG when p is outside [0, width * rows). */
+int rt_queue_pixel(int p, int width, int rows, int* row, int* x);
+
 int rt_get_stats(rt_ctx* ctx, rt_stats* out);   /* waits for the ctx's work */
 int rt_reset_stats(rt_ctx* ctx);
 

@@ -1291,6 +1291,14 @@ int rt_primary_hits(rt_ctx* c, int y0, int rows, uint64_t* keys, size_t count) {
     return 0;
 }
 
+int rt_queue_pixel(int p, int width, int rows, int* row, int* x) {
+    if (!row || !x) return fail(RT_ERR_ARG, "rt_queue_pixel: null argument");
+    if (width <= 0 || rows <= 0 || p < 0 || (long long)p >= (long long)width * rows)
+        return fail(RT_ERR_ARG, "rt_queue_pixel: index outside the pass");
+    queue_pixel(p, width, rows, row, x);
+    return 0;
+}
+
 int rt_bind_frame(rt_ctx* c, void* device_rgba, size_t bytes) {
     if (!c) return fail(RT_ERR_ARG, "rt_bind_frame: null ctx");
     if (!device_rgba) { c->frame = c->own_frame.p; return 0; }
