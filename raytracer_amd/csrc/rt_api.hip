@@ -145,11 +145,12 @@ struct rt_ctx {
     DevBuf<double> lvl_phong, lvl_child;   // [levels][3][cap]
     DevBuf<uint32_t> counts;       // [levels + 1]
     DevBuf<uint32_t> hit_offsets;  // [aux_grid + 1]: k_hit_offsets -> k_hit
-    DevBuf<uint8_t> ray_flags[2];     // [cap * max(1, n_lights)]
+    // [16 + cap * max(1, n_lights)]: the pair counter and the task counter (8 bytes each) in front of the
+    // per-ray flags, so that one fill clears all three before a launch
+    DevBuf<uint8_t> ray_flags[2];
     // scratch of the trace launches, one set per kind of query ([0] nearest hit, [1] shadow) so
     // that a level's shadow launches can run beside the next level's nearest-hit launches
     DevBuf<unsigned long long> pairs[2];
-    DevBuf<unsigned long long> pair_count[2];
     size_t pair_cap[2] = {0, 0};
     hipStream_t side_stream = nullptr;    // the shadow/Phong half of a level runs here
     std::vector<hipEvent_t> ev_hit, ev_phong;   // per level: k_hit done / k_phong done
@@ -255,10 +256,9 @@ int ensure_workspace(rt_ctx* c) {
     // room for 16 listed pairs per ray of the largest launch (a few are typical), 8 B each
     const size_t max_rays[2] = {want, shadow_rays};
     for (int m = 0; m < 2; m++) {
-        HIP_TRY(c->ray_flags[m].alloc(max_rays[m]));
+        HIP_TRY(c->ray_flags[m].alloc(max_rays[m] + 16));
         c->pair_cap[m] = std::min<size_t>(std::max<size_t>(max_rays[m] * 16, 1u << 20), 1u << 28);
         HIP_TRY(c->pairs[m].alloc(c->pair_cap[m]));
-        HIP_TRY(c->pair_count[m].alloc(2));   // [0] pairs listed, [1] the task counter
     }
     if (!c->side_stream) HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
     while ((int)c->ev_hit.size() < levels) {
@@ -326,11 +326,11 @@ int launch_trace(rt_ctx* c, TraceArgs A, hipStream_t st, size_t max_rays, bool c
     const bool light_bounds = MODE == 1 && c->shared_consts && c->pretest && c->bound_lights.n > 0;
     A.bound_lights = light_bounds ? c->bound_lights.p : nullptr;
     A.light_frame = light_bounds ? c->light_frame.p : nullptr;
-    A.ray_flags = c->ray_flags[MODE].p; A.pairs = c->pairs[MODE].p; A.pair_count = c->pair_count[MODE].p;
-    A.task_counter = (unsigned int*)(c->pair_count[MODE].p + 1);
+    A.pair_count = (unsigned long long*)c->ray_flags[MODE].p;
+    A.task_counter = (unsigned int*)(A.pair_count + 1);
+    A.ray_flags = c->ray_flags[MODE].p + 16; A.pairs = c->pairs[MODE].p;
     A.pair_cap = (unsigned int)c->pair_cap[MODE]; A.counters = c->counters.p; A.scan_all = c->force_exact;
-    HIP_TRY(hipMemsetAsync(c->pair_count[MODE].p, 0, 2 * sizeof(unsigned long long), st));
-    HIP_TRY(hipMemsetAsync(c->ray_flags[MODE].p, 0, std::min(c->ray_flags[MODE].n, max_rays), st));   // (no queue of the pass is longer)
+    HIP_TRY(hipMemsetAsync(c->ray_flags[MODE].p, 0, std::min(c->ray_flags[MODE].n, max_rays + 16), st));   // (no queue of the pass is longer)
     if (!c->force_exact && c->hs.n_regular > 0) {
         Timed t(c, st, (MODE == 0 && A.cone_camera && !c->use_bvh) ? 3 : MODE);
         if (c->use_bvh) {
@@ -1373,7 +1373,7 @@ void rt_free(rt_ctx* c) {
     for (int i = 0; i < 2; i++) { c->aux[i].release(); c->occluded[i].release(); }
     c->pixel_of_ray.release(); c->lvl_parent.release();
     c->lvl_obj.release(); c->lvl_phong.release(); c->lvl_child.release(); c->counts.release(); c->hit_offsets.release();
-    for (int i = 0; i < 2; i++) { c->ray_flags[i].release(); c->pairs[i].release(); c->pair_count[i].release(); }
+    for (int i = 0; i < 2; i++) { c->ray_flags[i].release(); c->pairs[i].release(); }
     for (auto e : c->ev_hit) (void)hipEventDestroy(e);
     for (auto e : c->ev_phong) (void)hipEventDestroy(e);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
