@@ -43,7 +43,7 @@ typedef struct rt_material {
  * row-major.  The caller computes inv and inv_t with the reference's own
  * mat4::inverse()/transpose() (algebra3.h:1130, 1123) so the bits agree. */
 typedef struct rt_transform {
-    double m[16], inv[16], inv_t[16];
+    double m[16], inv[16], inv_t[16];   /* m and inv must be affine: last row 0 0 0 1 (else RT_ERR_ARG) */
 } rt_transform;
 
 /* Light (raytracer.cpp:86-106).  For a directional light `pos` is the

@@ -84,6 +84,10 @@ template <class F> void parallel_ranges(size_t n, size_t parts, F&& body) {
 template <class T> struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }          // (a buffer that goes out of scope on an error path is not leaked)
     hipError_t alloc(size_t count) {
         release();
         n = count;
@@ -114,6 +118,32 @@ struct HostTri {
     int xf, axis;
 };
 
+// The per-pass workspace: queues, keys, per-level hit records, pair lists.  Every array is a
+// slice of ONE block of device memory (the context's own allocation, or the library's static
+// scratch array for the entry point that allocates nothing), cut by carve_workspace.
+struct Workspace {
+    size_t cap = 0;                // rays (pixels) per pass
+    int levels = 0;                // max_depth + 1
+    int occl_words = 1;
+    double* rayq[2] = {nullptr, nullptr};              // [6][cap] each
+    unsigned long long* keys[2] = {nullptr, nullptr};
+    double* aux[2] = {nullptr, nullptr};               // [6][cap], by level parity
+    uint32_t* occluded[2] = {nullptr, nullptr};        // [cap][occl_words], by level parity
+    int32_t* pixel_of_ray = nullptr;
+    int32_t *lvl_parent = nullptr, *lvl_obj = nullptr; // [levels][cap]
+    double *lvl_phong = nullptr, *lvl_child = nullptr; // [levels][3][cap]
+    uint32_t* counts = nullptr;                        // [levels + 2]
+    uint32_t* hit_offsets = nullptr;                   // [aux_grid + 1]: k_hit_offsets -> k_hit
+    // [16 + rays]: the pair counter and the task counter (8 bytes each) in front of the per-ray
+    // flags, so that one fill clears all three before a launch; one set per kind of query
+    // ([0] nearest hit, [1] shadow) so that a level's shadow launches can run beside the next
+    // level's nearest-hit launches
+    uint8_t* ray_flags[2] = {nullptr, nullptr};
+    size_t ray_flags_n[2] = {0, 0};
+    unsigned long long* pairs[2] = {nullptr, nullptr};
+    size_t pair_cap[2] = {0, 0};
+};
+
 struct rt_ctx {
     int device = 0;
     int n_cu = 0;
@@ -132,26 +162,9 @@ struct rt_ctx {
     uint32_t* frame = nullptr;     // own_frame.p or the caller's buffer
     DevBuf<DevCounters> counters;
 
-    // workspace, sized for `cap` rays per pass
-    size_t cap = 0;
-    int levels = 0;                // max_depth + 1
-    int occl_words = 1;
-    DevBuf<double> rayq[2];        // [6][cap] each
-    DevBuf<unsigned long long> keys[2];
-    DevBuf<double> aux[2];         // [6][cap], by level parity
-    DevBuf<uint32_t> occluded[2];  // [cap][occl_words], by level parity
-    DevBuf<int32_t> pixel_of_ray;
-    DevBuf<int32_t> lvl_parent, lvl_obj;   // [levels][cap]
-    DevBuf<double> lvl_phong, lvl_child;   // [levels][3][cap]
-    DevBuf<uint32_t> counts;       // [levels + 1]
-    DevBuf<uint32_t> hit_offsets;  // [aux_grid + 1]: k_hit_offsets -> k_hit
-    // [16 + cap * max(1, n_lights)]: the pair counter and the task counter (8 bytes each) in front of the
-    // per-ray flags, so that one fill clears all three before a launch
-    DevBuf<uint8_t> ray_flags[2];
-    // scratch of the trace launches, one set per kind of query ([0] nearest hit, [1] shadow) so
-    // that a level's shadow launches can run beside the next level's nearest-hit launches
-    DevBuf<unsigned long long> pairs[2];
-    size_t pair_cap[2] = {0, 0};
+    // workspace, sized for `ws.cap` rays per pass: one allocation, cut by carve_workspace
+    Workspace ws;
+    DevBuf<unsigned char> ws_block;
     hipStream_t side_stream = nullptr;    // the shadow/Phong half of a level runs here
     std::vector<hipEvent_t> ev_hit, ev_phong;   // per level: k_hit done / k_phong done
     int overlap = 1;                      // RT_OPT_OVERLAP
@@ -207,22 +220,65 @@ struct rt_ctx {
 
 namespace {
 
-RayQueue queue_of(DevBuf<double>& b, size_t cap) {
+RayQueue queue_of(double* b, size_t cap) {
     RayQueue q;
-    q.ox = b.p; q.oy = b.p + cap; q.oz = b.p + 2 * cap;
-    q.dx = b.p + 3 * cap; q.dy = b.p + 4 * cap; q.dz = b.p + 5 * cap;
+    q.ox = b; q.oy = b + cap; q.oz = b + 2 * cap;
+    q.dx = b + 3 * cap; q.dy = b + 4 * cap; q.dz = b + 5 * cap;
     return q;
 }
 
-LevelStore level_of(rt_ctx* c, int k) {
+LevelStore level_of(const Workspace& w, int k) {
     LevelStore l;
-    l.parent = c->lvl_parent.p + (size_t)k * c->cap;
-    l.obj = c->lvl_obj.p + (size_t)k * c->cap;
-    l.phong = c->lvl_phong.p + (size_t)k * 3 * c->cap;
-    l.child = c->lvl_child.p + (size_t)k * 3 * c->cap;
+    l.parent = w.lvl_parent + (size_t)k * w.cap;
+    l.obj = w.lvl_obj + (size_t)k * w.cap;
+    l.phong = w.lvl_phong + (size_t)k * 3 * w.cap;
+    l.child = w.lvl_child + (size_t)k * 3 * w.cap;
     return l;
 }
 
+// Cuts a workspace for passes of `cap` pixels out of the block at `base` (256-byte aligned
+// slices) and returns the bytes it takes; base == nullptr only measures.  The pair lists hold
+// `pairs_per_ray` entries per ray of the largest launch of their kind (a few are typical; a
+// list that runs full sends its rays through the full reference-precision scan instead), at
+// least `min_pairs`, at most 2^28.
+size_t carve_workspace(Workspace* w, unsigned char* base, size_t cap, int levels, int n_lights, int aux_grid,
+                       size_t pairs_per_ray, size_t min_pairs) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) -> unsigned char* {
+        unsigned char* at = base ? base + off : nullptr;
+        off += (bytes + 255) & ~(size_t)255;
+        return at;
+    };
+    Workspace t;
+    t.cap = cap; t.levels = levels;
+    t.occl_words = std::max(1, (n_lights + 31) / 32);
+    for (int i = 0; i < 2; i++) {
+        t.rayq[i] = (double*)take(6 * cap * sizeof(double));
+        t.keys[i] = (unsigned long long*)take(cap * sizeof(unsigned long long));
+        t.aux[i] = (double*)take(6 * cap * sizeof(double));
+        t.occluded[i] = (uint32_t*)take(cap * (size_t)t.occl_words * sizeof(uint32_t));
+    }
+    t.pixel_of_ray = (int32_t*)take(cap * sizeof(int32_t));
+    t.lvl_parent = (int32_t*)take((size_t)levels * cap * sizeof(int32_t));
+    t.lvl_obj = (int32_t*)take((size_t)levels * cap * sizeof(int32_t));
+    t.lvl_phong = (double*)take((size_t)levels * 3 * cap * sizeof(double));
+    t.lvl_child = (double*)take((size_t)levels * 3 * cap * sizeof(double));
+    t.counts = (uint32_t*)take((size_t)(levels + 2) * sizeof(uint32_t));
+    t.hit_offsets = (uint32_t*)take(((size_t)aux_grid + 1) * sizeof(uint32_t));
+    const size_t max_rays[2] = {cap, cap * (size_t)std::max(1, n_lights)};
+    for (int m = 0; m < 2; m++) {
+        t.ray_flags_n[m] = max_rays[m] + 16;
+        t.ray_flags[m] = (uint8_t*)take(t.ray_flags_n[m]);
+        t.pair_cap[m] = std::min<size_t>(std::max<size_t>(max_rays[m] * pairs_per_ray, min_pairs), (size_t)1 << 28);
+        t.pairs[m] = (unsigned long long*)take(t.pair_cap[m] * sizeof(unsigned long long));
+    }
+    if (w) *w = t;
+    return off;
+}
+
+// Sizes the context's own workspace for the current options.  Nothing in the context changes
+// unless every step succeeds: a failure leaves the previous workspace (or none) in place and
+// the caller returns the error without launching anything.
 int ensure_workspace(rt_ctx* c) {
     size_t frame_px = (size_t)c->hs.width * c->hs.height;
     // shadow rays of a pass are numbered with 31 bits
@@ -232,42 +288,36 @@ int ensure_workspace(rt_ctx* c) {
     // whole rows per pass
     want = std::max<size_t>(c->hs.width, want / c->hs.width * c->hs.width);
     int levels = c->hs.max_depth + 1;
-    if (c->cap == want && c->levels == levels) return 0;
-    c->cap = want; c->levels = levels;
-    c->occl_words = std::max(1, (c->hs.n_lights + 31) / 32);
-    for (int i = 0; i < 2; i++) {
-        HIP_TRY(c->rayq[i].alloc(6 * want));
-        HIP_TRY(c->keys[i].alloc(want));
-    }
-    for (int i = 0; i < 2; i++) {
-        HIP_TRY(c->aux[i].alloc(6 * want));
-        HIP_TRY(c->occluded[i].alloc(want * c->occl_words));
-    }
-    HIP_TRY(c->pixel_of_ray.alloc(want));
-    HIP_TRY(c->lvl_parent.alloc((size_t)levels * want));
-    HIP_TRY(c->lvl_obj.alloc((size_t)levels * want));
-    HIP_TRY(c->lvl_phong.alloc((size_t)levels * 3 * want));
-    HIP_TRY(c->lvl_child.alloc((size_t)levels * 3 * want));
-    HIP_TRY(c->counts.alloc(levels + 2));
-    HIP_TRY(c->hit_offsets.alloc((size_t)c->aux_grid + 1));
-    HIP_TRY(hipMemset(c->hit_offsets.p, 0, ((size_t)c->aux_grid + 1) * sizeof(uint32_t)));   // (its last entry counts finished blocks and must start at zero)
+    if (c->ws.cap == want && c->ws.levels == levels && c->ws_block.p) return 0;
     const size_t shadow_rays = want * (size_t)std::max(1, c->hs.n_lights);
-    if (shadow_rays >= (1ull << 31)) return fail(RT_ERR_RANGE, "pass too large: lower RT_OPT_PASS_PIXELS");
-    // room for 16 listed pairs per ray of the largest launch (a few are typical), 8 B each
-    const size_t max_rays[2] = {want, shadow_rays};
-    for (int m = 0; m < 2; m++) {
-        HIP_TRY(c->ray_flags[m].alloc(max_rays[m] + 16));
-        c->pair_cap[m] = std::min<size_t>(std::max<size_t>(max_rays[m] * 16, 1u << 20), 1u << 28);
-        HIP_TRY(c->pairs[m].alloc(c->pair_cap[m]));
-    }
+    if (shadow_rays >= (1ull << 31))
+        return fail(RT_ERR_RANGE, "pass too large (one row of shadow rays exceeds 2^31): fewer lights or a narrower frame");
     if (!c->side_stream) HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
-    while ((int)c->ev_hit.size() < levels) {
-        hipEvent_t a = nullptr, b = nullptr;
-        HIP_TRY(hipEventCreateWithFlags(&a, hipEventDisableTiming));
-        c->ev_hit.push_back(a);
-        HIP_TRY(hipEventCreateWithFlags(&b, hipEventDisableTiming));
-        c->ev_phong.push_back(b);
+    while ((int)c->ev_hit.size() < levels || (int)c->ev_phong.size() < levels) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        if (c->ev_hit.size() <= c->ev_phong.size()) c->ev_hit.push_back(e); else c->ev_phong.push_back(e);
     }
+    // room for 16 listed pairs per ray of the largest launch (a few are typical), 8 B each
+    const size_t bytes = carve_workspace(nullptr, nullptr, want, levels, c->hs.n_lights, c->aux_grid, 16, (size_t)1 << 20);
+    HIP_TRY(hipDeviceSynchronize());          // no launch may still use the block released here
+    c->ws = Workspace{};
+    c->ws_block.release();
+    hipError_t e = c->ws_block.alloc(bytes);
+    if (e != hipSuccess) {
+        c->ws_block.release();
+        return fail(RT_ERR_DEVICE, std::string("workspace of ") + std::to_string(bytes >> 20) + " MiB: " + hipGetErrorString(e) +
+                                       " (lower RT_OPT_PASS_PIXELS)");
+    }
+    Workspace w;
+    carve_workspace(&w, c->ws_block.p, want, levels, c->hs.n_lights, c->aux_grid, 16, (size_t)1 << 20);
+    // (the last entry of hit_offsets counts finished blocks and must start at zero)
+    e = hipMemset(w.hit_offsets, 0, ((size_t)c->aux_grid + 1) * sizeof(uint32_t));
+    if (e != hipSuccess) {
+        c->ws_block.release();
+        return fail(RT_ERR_DEVICE, std::string("workspace: ") + hipGetErrorString(e));
+    }
+    c->ws = w;
     return 0;
 }
 
@@ -298,8 +348,8 @@ void drain_spans(rt_ctx* c) {
 
 struct Timed {
     rt_ctx* c; hipStream_t st; int kind; hipEvent_t a = nullptr, b = nullptr;
-    Timed(rt_ctx* c_, hipStream_t st_, int kind_) : c(c_), st(st_), kind(kind_) {
-        if (c->profile) {
+    Timed(rt_ctx* c_, hipStream_t st_, int kind_, bool enabled = true) : c(c_), st(st_), kind(kind_) {
+        if (c->profile && enabled) {
             a = take_event(c); b = take_event(c);
             if (a && b) (void)hipEventRecord(a, st);
         }
@@ -313,8 +363,10 @@ struct Timed {
 };
 
 // Nearest hit (MODE 0) or shadow (MODE 1) of one queue: filter, listed pairs, the rest.
+// `events`: false for the entry point that allocates nothing (event timing creates events).
 template <int MODE>
-int launch_trace(rt_ctx* c, TraceArgs A, hipStream_t st, size_t max_rays, bool camera_rays = false) {
+int launch_trace(rt_ctx* c, const Workspace& W, TraceArgs A, hipStream_t st, size_t max_rays, bool camera_rays = false,
+                 bool events = true) {
     const DevScene* dsc = c->d_scene.p;
     A.shared_origin_a = (MODE == 0 && camera_rays && c->shared_consts) ? c->eye_a.p : nullptr;
     A.shared_dir_rinv = (MODE == 1 && c->shared_consts && c->dir_rinv.n > 0) ? c->dir_rinv.p : nullptr;
@@ -326,13 +378,13 @@ int launch_trace(rt_ctx* c, TraceArgs A, hipStream_t st, size_t max_rays, bool c
     const bool light_bounds = MODE == 1 && c->shared_consts && c->pretest && c->bound_lights.n > 0;
     A.bound_lights = light_bounds ? c->bound_lights.p : nullptr;
     A.light_frame = light_bounds ? c->light_frame.p : nullptr;
-    A.pair_count = (unsigned long long*)c->ray_flags[MODE].p;
+    A.pair_count = (unsigned long long*)W.ray_flags[MODE];
     A.task_counter = (unsigned int*)(A.pair_count + 1);
-    A.ray_flags = c->ray_flags[MODE].p + 16; A.pairs = c->pairs[MODE].p;
-    A.pair_cap = (unsigned int)c->pair_cap[MODE]; A.counters = c->counters.p; A.scan_all = c->force_exact;
-    HIP_TRY(hipMemsetAsync(c->ray_flags[MODE].p, 0, std::min(c->ray_flags[MODE].n, max_rays + 16), st));   // (no queue of the pass is longer)
+    A.ray_flags = W.ray_flags[MODE] + 16; A.pairs = W.pairs[MODE];
+    A.pair_cap = (unsigned int)W.pair_cap[MODE]; A.counters = c->counters.p; A.scan_all = c->force_exact;
+    HIP_TRY(hipMemsetAsync(W.ray_flags[MODE], 0, std::min(W.ray_flags_n[MODE], max_rays + 16), st));   // (no queue of the pass is longer)
     if (!c->force_exact && c->hs.n_regular > 0) {
-        Timed t(c, st, (MODE == 0 && A.cone_camera && !c->use_bvh) ? 3 : MODE);
+        Timed t(c, st, (MODE == 0 && A.cone_camera && !c->use_bvh) ? 3 : MODE, events);
         if (c->use_bvh) {
             BvhArgs ba;
             ba.bvh = c->bvh_groups.p; ba.nodes = c->bvh_nodes.p; ba.filt = (const float*)c->tri_filt.p;
@@ -360,7 +412,7 @@ int launch_trace(rt_ctx* c, TraceArgs A, hipStream_t st, size_t max_rays, bool c
         HIP_TRY(hipGetLastError());
         t.stop();
     }
-    Timed t(c, st, 2);
+    Timed t(c, st, 2, events);
     if (!c->force_exact && c->hs.n_regular > 0 && !c->use_bvh) {      // (the LBVH traversal lists no pairs)
         hipLaunchKernelGGL(k_exact_pairs<MODE>, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, dsc,
                            (const TriExact*)c->tri_exact.p, A);
@@ -436,15 +488,17 @@ int build_bvh(rt_ctx* c) {
 }
 
 // One pass: rows q0 .. q0+nrows of the pass's row sequence, nrows * width <= cap.
-int run_pass(rt_ctx* c, PassDesc pd, int nrows, hipStream_t st) {
+// `ws`: the workspace to use (nrows * width <= ws.cap).  `side_work`: false keeps every launch on
+// the caller's stream and records no event (the entry point that allocates nothing).
+int run_pass(rt_ctx* c, const Workspace& ws, PassDesc pd, int nrows, hipStream_t st, bool side_work = true) {
     const int W = c->hs.width;
     const int n_pix = nrows * W;
-    const int levels = c->levels;
+    const int levels = ws.levels;
     const DevScene* dsc = c->d_scene.p;
-    HIP_TRY(hipMemsetAsync(c->counts.p, 0, (levels + 2) * sizeof(uint32_t), st));
-    RayQueue q[2] = {queue_of(c->rayq[0], c->cap), queue_of(c->rayq[1], c->cap)};
-    hipLaunchKernelGGL(k_primary, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, dsc, pd, n_pix, q[0], c->keys[0].p,
-                       c->pixel_of_ray.p, c->frame, c->counts.p);
+    HIP_TRY(hipMemsetAsync(ws.counts, 0, (levels + 2) * sizeof(uint32_t), st));
+    RayQueue q[2] = {queue_of(ws.rayq[0], ws.cap), queue_of(ws.rayq[1], ws.cap)};
+    hipLaunchKernelGGL(k_primary, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, dsc, pd, n_pix, q[0], ws.keys[0],
+                       ws.pixel_of_ray, c->frame, ws.counts);
     HIP_TRY(hipGetLastError());
     // Per level: nearest hit -> k_hit on the caller's stream; shadow rays -> k_phong on the side
     // stream, beside the next level's nearest-hit launches (both only read what k_hit wrote).
@@ -452,29 +506,29 @@ int run_pass(rt_ctx* c, PassDesc pd, int nrows, hipStream_t st) {
     // timing on (RT_OPT_PROFILE) everything stays on one stream so that a kernel's duration is
     // its own.  Hit auxiliaries and occlusion bits alternate between two buffers by level
     // parity; k_hit of level k+2 waits for k_phong of level k before it overwrites them.
-    const bool overlap = c->overlap && !c->profile && levels > 1;
+    const bool overlap = side_work && c->overlap && !c->profile && levels > 1;
     hipStream_t sb = overlap ? c->side_stream : st;
     for (int k = 0; k < levels; k++) {
         const int cur = k & 1, nxt = cur ^ 1;
-        LevelStore lvl = level_of(c, k);
-        double* ab = c->aux[cur].p;
+        LevelStore lvl = level_of(ws, k);
+        double* ab = ws.aux[cur];
         HitAux aux;
-        aux.nx = ab; aux.ny = ab + c->cap; aux.nz = ab + 2 * c->cap;
-        aux.vx = ab + 3 * c->cap; aux.vy = ab + 4 * c->cap; aux.vz = ab + 5 * c->cap;
-        uint32_t* occl = c->occluded[cur].p;
+        aux.nx = ab; aux.ny = ab + ws.cap; aux.nz = ab + 2 * ws.cap;
+        aux.vx = ab + 3 * ws.cap; aux.vy = ab + 4 * ws.cap; aux.vz = ab + 5 * ws.cap;
+        uint32_t* occl = ws.occluded[cur];
         TraceArgs ta{};
-        ta.rays = q[cur]; ta.n_items = c->counts.p + k; ta.keys = c->keys[cur].p;
-        ta.occl_words = c->occl_words;
-        int rc = launch_trace<0>(c, ta, st, (size_t)n_pix, k == 0);
+        ta.rays = q[cur]; ta.n_items = ws.counts + k; ta.keys = ws.keys[cur];
+        ta.occl_words = ws.occl_words;
+        int rc = launch_trace<0>(c, ws, ta, st, (size_t)n_pix, k == 0, side_work);
         if (rc) return rc;
 
         if (overlap && k >= 2) HIP_TRY(hipStreamWaitEvent(st, c->ev_phong[k - 2], 0));
         HitArgs ha{};
-        ha.sc = dsc; ha.cur = q[cur]; ha.next = q[nxt]; ha.keys = c->keys[cur].p; ha.next_keys = c->keys[nxt].p;
-        ha.n_rays = c->counts.p + k; ha.hit_offsets = c->hit_offsets.p; ha.lvl = lvl; ha.aux = aux;
-        ha.occluded = occl; ha.occl_words = c->occl_words;
-        hipLaunchKernelGGL(k_hit_offsets, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, (const unsigned long long*)c->keys[cur].p,
-                           (const uint32_t*)(c->counts.p + k), c->hit_offsets.p, c->counts.p + k + 1);
+        ha.sc = dsc; ha.cur = q[cur]; ha.next = q[nxt]; ha.keys = ws.keys[cur]; ha.next_keys = ws.keys[nxt];
+        ha.n_rays = ws.counts + k; ha.hit_offsets = ws.hit_offsets; ha.lvl = lvl; ha.aux = aux;
+        ha.occluded = occl; ha.occl_words = ws.occl_words;
+        hipLaunchKernelGGL(k_hit_offsets, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, (const unsigned long long*)ws.keys[cur],
+                           (const uint32_t*)(ws.counts + k), ws.hit_offsets, ws.counts + k + 1);
         hipLaunchKernelGGL(k_hit, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, ha);
         HIP_TRY(hipGetLastError());
         if (overlap) {
@@ -484,15 +538,15 @@ int run_pass(rt_ctx* c, PassDesc pd, int nrows, hipStream_t st) {
 
         if (c->hs.n_lights > 0) {
             TraceArgs sa{};
-            sa.rays = q[nxt]; sa.n_items = c->counts.p + k + 1; sa.source_obj = lvl.obj;
-            sa.occluded = occl; sa.occl_words = c->occl_words;
-            rc = launch_trace<1>(c, sa, sb, (size_t)n_pix * (size_t)std::max(1, c->hs.n_lights));
+            sa.rays = q[nxt]; sa.n_items = ws.counts + k + 1; sa.source_obj = lvl.obj;
+            sa.occluded = occl; sa.occl_words = ws.occl_words;
+            rc = launch_trace<1>(c, ws, sa, sb, (size_t)n_pix * (size_t)std::max(1, c->hs.n_lights), false, side_work);
             if (rc) return rc;
         }
 
         PhongArgs pa{};
         pa.sc = dsc; pa.next = q[nxt]; pa.aux = aux; pa.lvl = lvl; pa.occluded = occl;
-        pa.occl_words = c->occl_words; pa.cap = (uint32_t)c->cap; pa.n_hits = c->counts.p + k + 1;
+        pa.occl_words = ws.occl_words; pa.cap = (uint32_t)ws.cap; pa.n_hits = ws.counts + k + 1;
         hipLaunchKernelGGL(k_phong, dim3(c->aux_grid), dim3(RT_BLOCK), 0, sb, pa);
         HIP_TRY(hipGetLastError());
         if (overlap) HIP_TRY(hipEventRecord(c->ev_phong[k], sb));
@@ -501,13 +555,13 @@ int run_pass(rt_ctx* c, PassDesc pd, int nrows, hipStream_t st) {
     if (overlap) HIP_TRY(hipStreamWaitEvent(st, c->ev_phong[levels - 1], 0));
     for (int k = levels - 1; k >= 0; k--) {
         FoldArgs fa{};
-        fa.sc = dsc; fa.lvl = level_of(c, k); fa.parent_lvl = level_of(c, k > 0 ? k - 1 : 0);
-        fa.cap = (uint32_t)c->cap; fa.n_hits = c->counts.p + k + 1; fa.level = k;
-        fa.pixel_of_ray = c->pixel_of_ray.p; fa.frame = c->frame;
+        fa.sc = dsc; fa.lvl = level_of(ws, k); fa.parent_lvl = level_of(ws, k > 0 ? k - 1 : 0);
+        fa.cap = (uint32_t)ws.cap; fa.n_hits = ws.counts + k + 1; fa.level = k;
+        fa.pixel_of_ray = ws.pixel_of_ray; fa.frame = c->frame;
         hipLaunchKernelGGL(k_fold, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, fa);
         HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_count, dim3(1), dim3(64), 0, st, dsc, (const uint32_t*)c->counts.p, levels, c->counters.p);
+    hipLaunchKernelGGL(k_count, dim3(1), dim3(64), 0, st, dsc, (const uint32_t*)ws.counts, levels, c->counters.p);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -525,12 +579,12 @@ int render_rows(rt_ctx* c, int y_start, int tile_rows, int stride_rows, int n_ti
         if (y0 >= H) break;
         total_rows += std::min<long long>(tile_rows, H - y0);
     }
-    const int rows_per_pass = (int)(c->cap / W);
+    const int rows_per_pass = (int)(c->ws.cap / W);
     c->last_stream = st;
     for (long long q0 = 0; q0 < total_rows; q0 += rows_per_pass) {
         int nrows = (int)std::min<long long>(rows_per_pass, total_rows - q0);
         PassDesc pd{y_start, tile_rows, stride_rows, (int)q0};
-        rc = run_pass(c, pd, nrows, st);
+        rc = run_pass(c, c->ws, pd, nrows, st);
         if (rc) return rc;
     }
     return 0;
@@ -818,8 +872,25 @@ extern "C" {
 
 const char* rt_last_error(void) { return g_err.c_str(); }
 
+// No exception may cross the C boundary (host allocations, host threads of the precomputation):
+// the entry points that can meet one turn it into an error code.
+#define RT_GUARD_BEGIN try {
+#define RT_GUARD_END(name)                                                                              \
+    } catch (const std::bad_alloc&) { return fail(RT_ERR_DEVICE, name ": out of host memory"); }       \
+      catch (const std::exception& e) { return fail(RT_ERR_DEVICE, std::string(name ": ") + e.what()); } \
+      catch (...) { return fail(RT_ERR_DEVICE, name ": unknown failure"); }
+
+static int upload_scene(rt_ctx** out, const rt_scene_desc* d);
 
 int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
+    RT_GUARD_BEGIN
+    return upload_scene(out, d);
+    RT_GUARD_END("rt_upload_scene")
+}
+
+}  // extern "C"
+
+static int upload_scene(rt_ctx** out, const rt_scene_desc* d) {
     if (!out || !d) return fail(RT_ERR_ARG, "rt_upload_scene: null argument");
     if (d->struct_size != sizeof(rt_scene_desc)) return fail(RT_ERR_ARG, "rt_upload_scene: struct_size mismatch");
     if (d->width <= 0 || d->height <= 0 || d->max_depth < 0 || d->max_depth > 64)
@@ -839,6 +910,17 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
         if (d->obj_transform[i] < 0 || d->obj_transform[i] >= d->n_transforms)
             return fail(RT_ERR_ARG, "rt_upload_scene: transform index out of range");
         if (d->obj_interp[i] && !d->obj_normals) return fail(RT_ERR_ARG, "rt_upload_scene: obj_normals missing");
+    }
+
+    // Every transform must be affine: the bounds and margins behind the FP32 filter are derived
+    // without a perspective divide (what parseSceneFile can build -- translations, rotations,
+    // scalings and their products, raytracer.cpp:806-824 -- always is).
+    for (int t = 0; t < d->n_transforms; t++) {
+        const double* rows[2] = {d->transforms[t].m + 12, d->transforms[t].inv + 12};
+        for (const double* r : rows)
+            if (!(r[0] == 0.0 && r[1] == 0.0 && r[2] == 0.0 && r[3] == 1.0))
+                return fail(RT_ERR_ARG, "rt_upload_scene: transform " + std::to_string(t) +
+                                            " is not affine (the last row of m and of inv must be 0 0 0 1)");
     }
 
     int ndev = 0;
@@ -1201,8 +1283,11 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
     return 0;
 }
 
+extern "C" {
+
 int rt_set_option(rt_ctx* c, int option, int64_t value) {
     if (!c) return fail(RT_ERR_ARG, "rt_set_option: null ctx");
+    RT_GUARD_BEGIN
     switch (option) {
         case RT_OPT_EXACT_ONLY: c->force_exact = value ? 1 : 0; return 0;
         case RT_OPT_PROFILE: c->profile = value ? 1 : 0; return 0;
@@ -1232,6 +1317,7 @@ int rt_set_option(rt_ctx* c, int option, int64_t value) {
             return 0;
         default: return fail(RT_ERR_ARG, "rt_set_option: unknown option");
     }
+    RT_GUARD_END("rt_set_option")
 }
 
 int rt_render_tile(rt_ctx* c, int y0, int rows, void* stream) {
@@ -1257,11 +1343,13 @@ int rt_primary_hits(rt_ctx* c, int y0, int rows, uint64_t* keys, size_t count) {
         return fail(RT_ERR_RANGE, "rt_primary_hits: rows outside the frame");
     const int W = c->hs.width;
     if (count < (size_t)rows * W) return fail(RT_ERR_RANGE, "rt_primary_hits: buffer too small");
+    RT_GUARD_BEGIN
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());          // renders still in flight on other streams use the same workspace
     int rc = ensure_workspace(c);
     if (rc) return rc;
-    const int rows_per_pass = (int)(c->cap / W);
+    const Workspace& ws = c->ws;
+    const int rows_per_pass = (int)(ws.cap / W);
     hipStream_t st = nullptr;
     const DevScene* dsc = c->d_scene.p;
     std::vector<uint64_t> queued;
@@ -1269,19 +1357,19 @@ int rt_primary_hits(rt_ctx* c, int y0, int rows, uint64_t* keys, size_t count) {
         const int nrows = std::min(rows_per_pass, rows - q0);
         const int n_pix = nrows * W;
         PassDesc pd{y0, rows, rows, q0};
-        HIP_TRY(hipMemsetAsync(c->counts.p, 0, (c->levels + 2) * sizeof(uint32_t), st));
-        RayQueue q = queue_of(c->rayq[0], c->cap);
-        hipLaunchKernelGGL(k_primary, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, dsc, pd, n_pix, q, c->keys[0].p,
-                           c->pixel_of_ray.p, c->frame, c->counts.p);
+        HIP_TRY(hipMemsetAsync(ws.counts, 0, (ws.levels + 2) * sizeof(uint32_t), st));
+        RayQueue q = queue_of(ws.rayq[0], ws.cap);
+        hipLaunchKernelGGL(k_primary, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, dsc, pd, n_pix, q, ws.keys[0],
+                           ws.pixel_of_ray, c->frame, ws.counts);
         HIP_TRY(hipGetLastError());
         TraceArgs ta{};
-        ta.rays = q; ta.n_items = c->counts.p; ta.keys = c->keys[0].p; ta.occl_words = c->occl_words;
-        rc = launch_trace<0>(c, ta, st, (size_t)n_pix, true);
+        ta.rays = q; ta.n_items = ws.counts; ta.keys = ws.keys[0]; ta.occl_words = ws.occl_words;
+        rc = launch_trace<0>(c, ws, ta, st, (size_t)n_pix, true);
         if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(st));
         // the queue is in tile order (queue_pixel); the caller's array is in scanline order
         queued.resize((size_t)n_pix);
-        HIP_TRY(hipMemcpy(queued.data(), c->keys[0].p, (size_t)n_pix * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(queued.data(), ws.keys[0], (size_t)n_pix * sizeof(uint64_t), hipMemcpyDeviceToHost));
         for (int p = 0; p < n_pix; p++) {
             int row, x;
             queue_pixel(p, W, nrows, &row, &x);
@@ -1289,6 +1377,7 @@ int rt_primary_hits(rt_ctx* c, int y0, int rows, uint64_t* keys, size_t count) {
         }
     }
     return 0;
+    RT_GUARD_END("rt_primary_hits")
 }
 
 int rt_queue_pixel(int p, int width, int rows, int* row, int* x) {
@@ -1369,11 +1458,7 @@ void rt_free(rt_ctx* c) {
     c->obj_material.release(); c->obj_transform.release(); c->obj_interp.release(); c->obj_geom.release();
     c->obj_normals.release(); c->materials.release(); c->lights.release(); c->own_frame.release();
     c->counters.release();
-    for (int i = 0; i < 2; i++) { c->rayq[i].release(); c->keys[i].release(); }
-    for (int i = 0; i < 2; i++) { c->aux[i].release(); c->occluded[i].release(); }
-    c->pixel_of_ray.release(); c->lvl_parent.release();
-    c->lvl_obj.release(); c->lvl_phong.release(); c->lvl_child.release(); c->counts.release(); c->hit_offsets.release();
-    for (int i = 0; i < 2; i++) { c->ray_flags[i].release(); c->pairs[i].release(); }
+    c->ws_block.release();
     for (auto e : c->ev_hit) (void)hipEventDestroy(e);
     for (auto e : c->ev_phong) (void)hipEventDestroy(e);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);

@@ -57,8 +57,7 @@ void deflate_band(Band& b, const uint8_t* rgba, int width, bool last, int level)
 
 }  // namespace
 
-extern "C" int rth_write_png(const char* path, const uint8_t* rgba, int width, int height) {
-    if (!path || !rgba || width <= 0 || height <= 0) return RT_ERR_ARG;
+static int write_png(const char* path, const uint8_t* rgba, int width, int height) {
     const size_t stride = (size_t)width * 4;
     if ((stride + 1) * 64 > 0x7fffffffu) return RT_ERR_RANGE;          // a band must fit zlib's 32-bit counts
     // bands of at least 64 rows (and at most 1 GiB), one thread each, at most 16 threads at a time
@@ -74,11 +73,20 @@ extern "C" int rth_write_png(const char* path, const uint8_t* rgba, int width, i
     }
     const unsigned hw = std::thread::hardware_concurrency();
     const int n_threads = std::max(1, std::min<int>(16, std::min<int>(n_bands, hw ? (int)hw : 4)));
+    // (a band whose worker ran out of memory stays !ok; a thread that cannot be started leaves
+    // its bands to the calling thread)
+    auto work = [&](int t) {
+        for (int k = t; k < n_bands; k += n_threads) {
+            try { deflate_band(bands[k], rgba, width, k == n_bands - 1, 6); } catch (...) { bands[k].ok = false; }
+        }
+    };
     std::vector<std::thread> pool;
-    for (int t = 0; t < n_threads; t++)
-        pool.emplace_back([&, t]() {
-            for (int k = t; k < n_bands; k += n_threads) deflate_band(bands[k], rgba, width, k == n_bands - 1, 6);
-        });
+    pool.reserve(n_threads);
+    int started = 0;
+    try {
+        for (; started < n_threads; started++) pool.emplace_back(work, started);
+    } catch (...) {}
+    for (int t = started; t < n_threads; t++) work(t);
     for (auto& th : pool) th.join();
 
     size_t zbytes = 2 + 4;
@@ -124,4 +132,14 @@ extern "C" int rth_write_png(const char* path, const uint8_t* rgba, int width, i
     const size_t w = fwrite(png.data(), 1, png.size(), f);
     fclose(f);
     return w == png.size() ? 0 : RT_ERR_ARG;
+}
+
+// No exception crosses the C boundary.
+extern "C" int rth_write_png(const char* path, const uint8_t* rgba, int width, int height) {
+    if (!path || !rgba || width <= 0 || height <= 0) return RT_ERR_ARG;
+    try {
+        return write_png(path, rgba, width, height);
+    } catch (...) {
+        return RT_ERR_ARG;
+    }
 }

@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <memory>
 #include <utility>
+#include <exception>
 #include <fstream>
 #include <sstream>
 #include <string>
@@ -324,10 +325,20 @@ struct MappedFile {
 
 template <class F> void for_chunks(size_t n, int n_threads, F&& body) {
     if (n_threads <= 1 || n <= 1) { for (size_t k = 0; k < n; k++) body(k); return; }
+    // An exception inside a worker (out of memory while a chunk's arrays grow) is carried back to
+    // the caller; a thread that cannot be started leaves its share to the calling thread.
+    std::vector<std::exception_ptr> failed((size_t)n_threads);
+    auto work = [&](int t) {
+        try { for (size_t k = (size_t)t; k < n; k += (size_t)n_threads) body(k); }
+        catch (...) { failed[(size_t)t] = std::current_exception(); }
+    };
     std::vector<std::thread> pool;
-    for (int t = 0; t < n_threads; t++)
-        pool.emplace_back([&, t]() { for (size_t k = (size_t)t; k < n; k += (size_t)n_threads) body(k); });
+    pool.reserve((size_t)n_threads);
+    int started = 0;
+    try { for (; started < n_threads; started++) pool.emplace_back(work, started); } catch (...) {}
+    for (int t = started; t < n_threads; t++) work(t);
     for (auto& th : pool) th.join();
+    for (auto& e : failed) if (e) std::rethrow_exception(e);
 }
 
 int Builder::load_obj(const std::string& name) {
@@ -527,17 +538,35 @@ template <class T> void put(std::vector<unsigned char>& out, const T* p, size_t 
 
 extern "C" {
 
+// No exception may cross the C boundary (an allocation that fails, a thread that cannot be
+// started): every entry point turns one into an error code.
+#define RTH_GUARD_BEGIN try {
+#define RTH_GUARD_END(name)                                                                       \
+    } catch (const std::bad_alloc&) { return fail(RT_ERR_ARG, name ": out of host memory"); }    \
+      catch (const std::exception& e) { return fail(RT_ERR_ARG, std::string(name ": ") + e.what()); } \
+      catch (...) { return fail(RT_ERR_ARG, name ": unknown failure"); }
+
 int rth_load_scene(rth_scene** out, const char* scene_path, int width, int height, int max_depth, float eps) {
     if (!out || !scene_path || width <= 0 || height <= 0) return fail(RT_ERR_ARG, "rth_load_scene: bad argument");
-    rth_scene* s = new rth_scene();
-    int rc = parse_scene(s, scene_path, width, height, max_depth, eps);
-    if (rc) { delete s; return rc; }
+    rth_scene* s = nullptr;
+    try {
+        s = new rth_scene();
+        int rc = parse_scene(s, scene_path, width, height, max_depth, eps);
+        if (rc) { delete s; return rc; }
+    } catch (const std::exception& e) {
+        delete s;
+        return fail(RT_ERR_ARG, std::string("rth_load_scene: ") + e.what());
+    } catch (...) {
+        delete s;
+        return fail(RT_ERR_ARG, "rth_load_scene: unknown failure");
+    }
     *out = s;
     return 0;
 }
 
 int rth_save_blob(const rth_scene* s, const char* path) {
     if (!s || !path) return fail(RT_ERR_ARG, "rth_save_blob: bad argument");
+    RTH_GUARD_BEGIN
     std::vector<unsigned char> b;
     const rt_scene_desc& d = s->d;
     put(b, "RTSD", 4);
@@ -561,10 +590,13 @@ int rth_save_blob(const rth_scene* s, const char* path) {
     size_t w = fwrite(b.data(), 1, b.size(), f);
     fclose(f);
     return w == b.size() ? 0 : fail(RT_ERR_ARG, "short write");
+    RTH_GUARD_END("rth_save_blob")
 }
 
 int rth_load_blob(rth_scene** out, const char* path) {
     if (!out || !path) return fail(RT_ERR_ARG, "rth_load_blob: bad argument");
+    rth_scene* s = nullptr;
+    try {
     FILE* f = fopen(path, "rb");
     if (!f) return fail(RT_ERR_ARG, std::string("cannot read ") + path);
     std::vector<unsigned char> b;
@@ -582,12 +614,20 @@ int rth_load_blob(rth_scene** out, const char* path) {
     char magic[4];
     int32_t hdr[4], cnt[4];
     float e[2];
-    rth_scene* s = new rth_scene();
+    s = new rth_scene();
     rt_scene_desc& d = s->d;
     bool ok = take(magic, 4) && std::memcmp(magic, "RTSD", 4) == 0 && take(hdr, 16) && hdr[0] == 1 &&
               take(e, 8) && take(cnt, 16) && take(d.cam_eye, 24) && take(d.cam_ll, 24) && take(d.cam_lr, 24) &&
               take(d.cam_ul, 24) && take(d.cam_ur, 24) && take(d.ambient, 24);
     if (ok) ok = cnt[0] >= 0 && cnt[1] >= 0 && cnt[2] >= 0 && cnt[3] >= 0;
+    if (ok) {
+        // the counts come from the file: the arrays they announce must fit into what is left of it
+        // before anything is sized from them
+        const size_t left = b.size() - off;
+        const size_t need = (size_t)cnt[0] * (16 + 144) + (size_t)cnt[1] * sizeof(rt_material) +
+                            (size_t)cnt[2] * sizeof(rt_transform) + (size_t)cnt[3] * sizeof(rt_light);
+        ok = need <= left;
+    }
     if (ok) {
         d.width = hdr[1]; d.height = hdr[2]; d.max_depth = hdr[3];
         d.eps = e[0]; d.shadow_eps = e[1];
@@ -605,6 +645,13 @@ int rth_load_blob(rth_scene** out, const char* path) {
     }
     if (!ok) { delete s; return fail(RT_ERR_ARG, std::string("malformed RTSD blob ") + path); }
     s->seal();
+    } catch (const std::exception& e) {
+        delete s;
+        return fail(RT_ERR_ARG, std::string("rth_load_blob: ") + e.what());
+    } catch (...) {
+        delete s;
+        return fail(RT_ERR_ARG, "rth_load_blob: unknown failure");
+    }
     *out = s;
     return 0;
 }

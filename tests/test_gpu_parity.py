@@ -267,6 +267,43 @@ def test_edge_cases():
     r.close()
 
 
+def test_workspace_that_cannot_be_sized_fails_every_time_and_launches_nothing(tmp_path):
+    """One row of shadow rays beyond 2^31 (a very wide frame under very many lights) cannot be numbered:
+    the render call fails with RT_ERR_RANGE, and so does the next one -- the context must not come to
+    believe that its workspace exists.  A context whose workspace does fit still renders afterwards."""
+    from raytracer_amd.render import Renderer, DeviceError
+    lines = ["cam 0 0 2 -1 -1 1 1 -1 1 -1 1 1 1 1 1", "lta 1 1 1", "mat 1 1 1 1 1 1 1 1 1 5 0 0 0", "sph 0 0 0 .5"]
+    lines += ["ltd 0 -1 %d 0.001 0.001 0.001" % (k + 1) for k in range(2048)]
+    path = os.path.join(str(tmp_path), "wide.scene")
+    open(path, "w").write("\n".join(lines) + "\n")
+    r = Renderer(Scene.load(path, 1 << 20, 1, 0))
+    for _ in range(2):
+        with pytest.raises(DeviceError) as e:
+            r.render_tile(0, 1)
+        assert "(-3)" in str(e.value)
+    with pytest.raises(DeviceError):
+        r.primary_hits(0, 1)
+    r.close()
+    img, st = gpu_render(Scene.load(path, 64, 4, 0))
+    assert st["rays_shadow"] == 2048 * st["hits"] and st["hits"] > 0
+
+
+def test_transform_that_is_not_affine_is_refused():
+    """The margins of the FP32 filter are derived without a perspective divide: a transform whose last
+    row is not 0 0 0 1 is an argument error, not a wrong picture."""
+    import ctypes as C
+    from raytracer_amd.render import Renderer, DeviceError
+    sc = Scene.load(scene_file("mixed_xf"), 16, 12, 1)
+    assert sc.desc.n_transforms > 1
+    keep = sc.desc.transforms[1].m[12]
+    sc.desc.transforms[1].m[12] = 0.25
+    with pytest.raises(DeviceError) as e:
+        Renderer(sc)
+    assert "(-1)" in str(e.value) and "affine" in str(e.value)
+    sc.desc.transforms[1].m[12] = keep
+    Renderer(sc).close()
+
+
 def test_more_than_32_lights(oracle, tmp_path):
     """Occlusion bits take one 32-bit word per 32 lights: 40 point and directional lights over a
     small mesh and a sphere, brute force and LBVH, against the oracle."""

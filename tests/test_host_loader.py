@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 from raytracer_amd import Scene, write_png
+from raytracer_amd.scene import SceneError
 from tests import oracle_api
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -192,6 +193,29 @@ def _model_obj_parse(text):
             nn = [norms[i] if with_n and 0 <= i < len(norms) else (0.0, 0.0, 0.0) for i in ni]
             faces.append((sum(map(list, g), []), sum(map(list, nn), []), int(with_n)))
     return faces
+
+
+def test_blob_with_counts_beyond_its_size_is_refused(tmp_path):
+    """A truncated or corrupt RTSD header must not size anything from its counts: an error, no abort,
+    no allocation of gigabytes."""
+    import struct
+    sc = Scene.load(os.path.join(ROOT, "scenes", "inputs", "input-05"), 8, 8)
+    good = tmp_path / "good.rtsd"
+    sc.save_blob(str(good))
+    data = bytearray(open(good, "rb").read())
+    # counts sit after "RTSD", i32 version/width/height/depth, f32 eps/shadow_eps
+    for bad in ((2 ** 31 - 1, 1, 1, 1), (1, 2 ** 31 - 1, 1, 1), (1, 1, 2 ** 31 - 1, 1), (1, 1, 1, 2 ** 31 - 1)):
+        b = bytearray(data)
+        b[28:44] = struct.pack("<4i", *bad)
+        p = tmp_path / "bad.rtsd"
+        open(p, "wb").write(bytes(b))
+        with pytest.raises(SceneError):
+            Scene.load_blob(str(p))
+    p = tmp_path / "short.rtsd"
+    open(p, "wb").write(bytes(data[:60]))
+    with pytest.raises(SceneError):
+        Scene.load_blob(str(p))
+    Scene.load_blob(str(good)).close()
 
 
 def test_obj_chunks_parse_like_one_pass(tmp_path, monkeypatch):
