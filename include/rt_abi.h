@@ -159,6 +159,18 @@ int rt_render_tile(rt_ctx* ctx, int y0, int rows, void* stream);
  * an N-GPU job calls it with first_tile = rank, tile_step = N. */
 int rt_render_tiles(rt_ctx* ctx, int first_tile, int tile_rows, int tile_step, void* stream);
 
+/* rt_render_tile for callers that cannot allocate device memory at the time of the call (code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the same
+ * kernels, with the workspace (ray queues, keys, per-level hit records, pair lists) taken from a
+ * static array of 64 MiB that the library holds on every GPU it runs on from load to process
+ * exit, so the call itself performs no hipMalloc / hipFree, creates no stream and no event, and
+ * runs every launch on `stream`.  No counterpart in the reference.  The tile is traced in one
+ * pass and must fit the array: rows * width * (about 0.4 KB + 56 B per level + 0.1 KB per light);
+ * a larger tile fails with RT_ERR_RANGE and a message that names the largest row count that
+ * fits -- the caller splits the frame.  Results are identical to rt_render_tile's.  All calls on
+ * one GPU share that GPU's array (also across contexts): calls that overlap in time race. */
+int rt_render_tile_noalloc(rt_ctx* ctx, int y0, int rows, void* stream);
+
 /* Use caller-owned device memory (width*height*4 bytes) as the frame, e.g. a
  * tensor that a collective will read.  NULL returns to the internal frame. */
 int rt_bind_frame(rt_ctx* ctx, void* device_rgba, size_t bytes);

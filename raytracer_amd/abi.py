@@ -64,7 +64,7 @@ class RtStats(C.Structure):
 
 HOST_SYMBOLS = ["rth_load_scene", "rth_load_blob", "rth_save_blob", "rth_desc", "rth_free_scene",
                 "rth_write_png", "rth_last_error"]
-DEVICE_SYMBOLS = ["rt_upload_scene", "rt_set_option", "rt_render_tile", "rt_render_tiles",
+DEVICE_SYMBOLS = ["rt_upload_scene", "rt_set_option", "rt_render_tile", "rt_render_tiles", "rt_render_tile_noalloc",
                   "rt_bind_frame", "rt_download", "rt_primary_hits", "rt_queue_pixel", "rt_get_stats", "rt_reset_stats", "rt_device_info",
                   "rt_free", "rt_last_error"]
 
@@ -117,6 +117,8 @@ def device_lib():
         lib.rt_set_option.restype = C.c_int
         lib.rt_render_tile.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         lib.rt_render_tile.restype = C.c_int
+        lib.rt_render_tile_noalloc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        lib.rt_render_tile_noalloc.restype = C.c_int
         lib.rt_render_tiles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         lib.rt_render_tiles.restype = C.c_int
         lib.rt_bind_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]

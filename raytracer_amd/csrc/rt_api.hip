@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -106,6 +107,31 @@ template <class T> struct DevBuf {
     }
 };
 
+}  // namespace
+
+// Workspace of rt_render_tile_noalloc: device memory the library holds from the moment it is
+// loaded until the process ends, on every GPU it runs on, so that the call itself allocates
+// nothing.  Host code never uses the array's name as an address: rt_upload_scene resolves the
+// current device's copy once (hipGetSymbolAddress) and everything goes through that pointer.
+#define RT_SCRATCH_BYTES ((size_t)64 << 20)
+#define RT_SCRATCH_MAX_DEVICES 64
+static __device__ __align__(256) unsigned char scratch[RT_SCRATCH_BYTES];
+
+namespace {
+std::mutex g_scratch_mutex;
+void* g_scratch_ptr[RT_SCRATCH_MAX_DEVICES];       // per device: address of its copy of `scratch`
+
+// With `device` current: the address of that device's copy of the scratch array.
+int resolve_scratch(int device) {
+    if (device < 0 || device >= RT_SCRATCH_MAX_DEVICES) return 0;      // (such a device has no static workspace)
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[device]) return 0;
+    void* ptr = nullptr;
+    HIP_TRY(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) return fail(RT_ERR_DEVICE, "hipGetSymbolAddress(scratch) returned a null address");
+    g_scratch_ptr[device] = ptr;
+    return 0;
+}
 }  // namespace
 
 // One triangle as the host keeps it: the reference-precision record and the filter record in
@@ -1279,6 +1305,8 @@ static int upload_scene(rt_ctx** out, const rt_scene_desc* d) {
         c->filter_grid[m] = c->n_cu * std::min(nb, 8);
     }
     c->aux_grid = c->n_cu * 8;
+    // this device's copy of the static workspace (for rt_render_tile_noalloc)
+    if (int rc = resolve_scratch(c->device)) return bail(rc);
     *out = c;
     return 0;
 }
@@ -1335,6 +1363,43 @@ int rt_render_tiles(rt_ctx* c, int first_tile, int tile_rows, int tile_step, voi
     if (first_tile >= n_total) return 0;
     const int n_mine = (n_total - first_tile + tile_step - 1) / tile_step;
     return render_rows(c, first_tile * tile_rows, tile_rows, tile_step * tile_rows, n_mine, (hipStream_t)stream);
+}
+
+int rt_render_tile_noalloc(rt_ctx* c, int y0, int rows, void* stream) {
+    if (!c) return fail(RT_ERR_ARG, "rt_render_tile_noalloc: null ctx");
+    if (rows < 0 || y0 < 0 || (long long)y0 + rows > c->hs.height)
+        return fail(RT_ERR_RANGE, "rt_render_tile_noalloc: rows outside the frame");
+    if (rows == 0) return 0;
+    if (c->device < 0 || c->device >= RT_SCRATCH_MAX_DEVICES || !g_scratch_ptr[c->device])
+        return fail(RT_ERR_STATE, "rt_render_tile_noalloc: no static workspace on this device");
+    unsigned char* base = (unsigned char*)g_scratch_ptr[c->device];      // this device's copy, never the array's name
+    const int W = c->hs.width, levels = c->hs.max_depth + 1, lights = c->hs.n_lights;
+    // the whole tile is one pass; 8 listed pairs per ray (a list that runs full costs time, not pixels)
+    const size_t pixels = (size_t)rows * (size_t)W;
+    const size_t need = carve_workspace(nullptr, nullptr, pixels, levels, lights, c->aux_grid, 8, 0);
+    if (need > RT_SCRATCH_BYTES || pixels * (size_t)std::max(1, lights) >= ((size_t)1 << 31)) {
+        // largest row count of this scene that fits (the size grows monotonically with the rows)
+        int lo = 0, hi = rows;
+        while (lo + 1 < hi) {
+            const int mid = lo + (hi - lo) / 2;
+            if (carve_workspace(nullptr, nullptr, (size_t)mid * W, levels, lights, c->aux_grid, 8, 0) <= RT_SCRATCH_BYTES) lo = mid; else hi = mid;
+        }
+        char msg[256];
+        snprintf(msg, sizeof msg, "rt_render_tile_noalloc: %d rows of %d pixels need %zu bytes of workspace, the static workspace "
+                 "holds %zu (at most %d rows per call for this scene's depth and lights)", rows, W, need, (size_t)RT_SCRATCH_BYTES, lo);
+        return fail(RT_ERR_RANGE, msg);
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    Workspace ws;
+    carve_workspace(&ws, base, pixels, levels, lights, c->aux_grid, 8, 0);
+    // The array keeps whatever the previous call left in it, at whatever offsets that call's sizes
+    // put it: the one slice that must start at zero (the count of finished blocks behind the
+    // hit offsets) is cleared here; queue lengths, counters and flags are cleared by the pass.
+    HIP_TRY(hipMemsetAsync(ws.hit_offsets, 0, ((size_t)c->aux_grid + 1) * sizeof(uint32_t), st));
+    c->last_stream = st;
+    PassDesc pd{y0, rows, rows, 0};
+    return run_pass(c, ws, pd, rows, st, /*side_work=*/false);
 }
 
 int rt_primary_hits(rt_ctx* c, int y0, int rows, uint64_t* keys, size_t count) {

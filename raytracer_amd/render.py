@@ -43,6 +43,11 @@ class Renderer:
         _check(self._lib, self._lib.rt_render_tile(self._ctx, int(y0), int(rows), C.c_void_p(stream or 0)),
                "rt_render_tile")
 
+    def render_tile_noalloc(self, y0, rows, stream=None):
+        """rt_render_tile through the library's static workspace: the call allocates nothing."""
+        _check(self._lib, self._lib.rt_render_tile_noalloc(self._ctx, int(y0), int(rows), C.c_void_p(stream or 0)),
+               "rt_render_tile_noalloc")
+
     def render_tiles(self, first_tile, tile_rows, tile_step, stream=None):
         _check(self._lib, self._lib.rt_render_tiles(self._ctx, int(first_tile), int(tile_rows), int(tile_step),
                                                     C.c_void_p(stream or 0)), "rt_render_tiles")
