@@ -22,7 +22,7 @@ $(PKG)/librt_host.so: $(HOST_SRC) include/rt_host.h include/rt_abi.h
 # the FP32 filter asks for its FMAs explicitly.
 $(PKG)/libraytracer_amd.so: $(HIP_SRC) $(HIP_HDR)
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -Iinclude -I$(PKG)/csrc \
-	  -o $@ $(HIP_SRC)
+	  $(EXTRA) -o $@ $(HIP_SRC)
 
 # The host driver (the reference's main): links both libraries, found at run time next to itself.
 $(PKG)/rt_render: $(PKG)/host/rt_cli.cpp $(PKG)/librt_host.so $(PKG)/libraytracer_amd.so include/rt_abi.h include/rt_host.h

@@ -36,6 +36,23 @@ sys.path.insert(0, ROOT)
 FLOP_TRI, FLOP_SPH = 42.0, 28.0          # per ray-primitive test, FMA = 2
 PEAK_FP32_VALU = 157.3e12                # 256 CU x 128 lanes x 2 x 2.4 GHz
 
+# Executed FP32 operations per test of each stage of the default (bounded) scans, counted from the
+# kernels' arithmetic (rt_kernels.h: filter_range / filter_z2; FMA = 2, multiply / add / reciprocal /
+# square root / divide = 1, compare / min / max / select = 0).  Per kind of scan:
+#   group  one (bundle of rays, triangle) question of the once-per-64-triangles judgement, per lane
+#   bound  one per-ray bounding-sphere test
+#   tri    one FP32 triangle test as that scan executes it (the shared origin of camera rays saves the
+#          plane distance, the shared direction of a directional light the denominator and its reciprocal;
+#          42 is the algorithmic price of the full test by the usual convention, 29 what it executes)
+STAGE_FLOP = {
+    "camera":             {"group": 25.0, "bound": 5.0, "tri": 23.0},
+    "shadow_point":       {"group": 43.0, "bound": 5.0, "tri": 29.0},
+    "shadow_directional": {"group": 33.0, "bound": 4.0, "tri": 23.0},
+    "reflection":         {"group": 40.0, "bound": 22.0, "tri": 29.0},
+    "plain_nearest":      {"group": 0.0, "bound": 0.0, "tri": 29.0},
+    "plain_shadow":       {"group": 0.0, "bound": 0.0, "tri": 29.0},
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -203,6 +220,17 @@ def main():
         st = st_default
     r.set_option(abi.RT_OPT_PROFILE, 0)
 
+    # One more frame of the default configuration in the counting instances of the scan kernels
+    # (RT_OPT_WORK_COUNTERS): the work the timed frames execute, stage by stage.
+    work = None
+    if not args.exact_only:
+        r.reset_stats()
+        r.set_option(abi.RT_OPT_WORK_COUNTERS, 1)
+        step()
+        fence()
+        work = r.stats()["scan_work"]
+        r.set_option(abi.RT_OPT_WORK_COUNTERS, 0)
+
     # The same frames again through the optional LBVH (same rays, same pixels; reported beside
     # the brute-force headline, which is what the roofline describes).
     lbvh = None
@@ -276,6 +304,43 @@ def main():
             "exact_retests_per_ray": sd["exact_tests"] / max(1, rays_local),
             "note": "the timed configuration: bounding-sphere tests in front of the triangle test; the 42-FLOP price "
                     "of a pair is the triangle test's, so these figures are not roofline fractions"}
+        # Executed work of the timed configuration: counts of one frame (they do not vary from frame to
+        # frame) x the stage prices above, over the scan's duration per frame in the serialised leg.
+        executed = None
+        if work is not None:
+            def merged(kinds):
+                out = {}
+                for k in kinds:
+                    for name, v in work[k].items():
+                        out[name] = out.get(name, 0) + v
+                return out
+
+            def executed_scan(kinds, ms_per_frame, nominal_pairs):
+                w = merged(kinds)
+                flop = sum(work[k]["group_tests"] * STAGE_FLOP[k]["group"] + work[k]["ray_bound_tests"] * STAGE_FLOP[k]["bound"] +
+                           work[k]["tri_tests"] * STAGE_FLOP[k]["tri"] for k in kinds)
+                tflops = flop / (ms_per_frame * 1e-3) / 1e12 if ms_per_frame > 0 else 0.0
+                return {"ms_per_step": ms_per_frame, "nominal_pairs_per_step": nominal_pairs,
+                        "executed_per_step": {"tasks": w["tasks"], "groups_of_64_judged": w["groups"],
+                                              "groups_live": w["groups_live"], "group_tests": w["group_tests"],
+                                              "batches_of_4_evaluated": w["batches"], "per_ray_bounding_tests": w["ray_bound_tests"],
+                                              "batches_with_a_triangle_test": w["batches_tested"],
+                                              "fp32_triangle_tests": w["tri_tests"],
+                                              "fp32_triangle_tests_in_lanes_that_asked": w["tri_tests_wanted"],
+                                              "pairs_listed": w["listed"]},
+                        "executed_flop_per_step": flop, "executed_tflops": tflops, "frac_of_peak": tflops * 1e12 / PEAK_FP32_VALU}
+            sms, steps = sd["scan_ms"], max(1, args.steps)
+            executed = {
+                "camera_rays": executed_scan(["camera"], sms["camera"] / steps, cam_tests // steps),
+                "reflection_rays": executed_scan(["reflection"], sms["reflection"] / steps,
+                                                 (sd["closest_tests"] - cam_tests) // steps),
+                "shadow_rays": executed_scan(["shadow_point", "shadow_directional"],
+                                             (sms["shadow_point"] + sms["shadow_directional"]) / steps,
+                                             sd["anyhit_tests"] // steps),
+                "stage_flop": STAGE_FLOP,
+                "note": "counts from one frame in the counting instances of the scan kernels (RT_OPT_WORK_COUNTERS), "
+                        "durations from the serialised leg (HIP events); whole-wave counts: a test a wave executes "
+                        "for one asking lane occupies all 64"}
         n_cu, clock_khz = r.device_info()
         device_peak = (n_cu * 128 * 2 * clock_khz * 1e3) if clock_khz else None
         line = {
@@ -299,26 +364,44 @@ def main():
                                           "shadow": n_shadow // args.steps,
                                           "note": "traced = reference-equivalent: every ray the reference's traceRay / "
                                                   "traceShadowRay would be called with, no path pruned"}},
-            "roofline": {"bound": "valu_fp32", "kernel": dom, "achieved": achieved / 1e12, "peak": PEAK_FP32_VALU / 1e12,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU,
-                         "peak_from_device_properties": {"compute_units": n_cu,
-                                                         "clock_mhz": clock_khz / 1e3 if clock_khz else None,
-                                                         "tflops": device_peak / 1e12 if device_peak else None},
-                         # (the committed PMC pass is a 1-GPU run: its per-launch bytes describe N = 1 only)
-                         "traffic": measured_traffic(dom, launches / max(1, args.steps)) if world == 1 and launches else None,
-                         "kernel_ms_avg": ms / max(1, launches), "launches": launches,
-                         "timing": "HIP events on the launch stream, K frames after the timed region with RT_OPT_BOUNDING_TESTS = 0 "
-                                   "and the library's two streams serialised (the default configuration takes %.2f ms per "
-                                   "frame serialised)" % (serial_elapsed / args.steps * 1e3),
-                         "flop_per_test": flop_per_test, "tests_per_launch": tests / max(1, launches),
-                         "both_filter_kernels_tflops": both / 1e12,
-                         "default_scans": default_scans,
-                         "filter_ms_per_step": both_ms / args.steps,
-                         "reference_precision_kernels_ms_per_step": st["exact_ms"] / args.steps,
-                         "exact_retests_per_ray": st["exact_tests"] / max(1, rays_local),
-                         "nominal_tests_per_step": (st["closest_tests"] + st["anyhit_tests"]) / max(1, args.steps),
-                         "executed_reference_precision_tests_per_step": st["exact_tests"] / max(1, args.steps)},
+            "roofline": None,
         }
+        plain = {"kernel": dom, "achieved": achieved / 1e12, "peak": PEAK_FP32_VALU / 1e12, "unit": "TFLOP/s",
+                 "frac": achieved / PEAK_FP32_VALU,
+                 "what": "the scan in which every ray x triangle pair takes the FP32 triangle test (RT_OPT_BOUNDING_TESTS = 0), "
+                         "priced at the algorithmic 42 FLOP per test; NOT the timed configuration (it takes %.1f ms per frame)"
+                         % (both_ms / args.steps),
+                 # (the committed PMC pass is a 1-GPU run: its per-launch bytes describe N = 1 only)
+                 "traffic": measured_traffic(dom, launches / max(1, args.steps)) if world == 1 and launches else None,
+                 "traffic_source": "replayed from the committed PMC summary under profiles/ (not measured in this run)",
+                 "kernel_ms_avg": ms / max(1, launches), "launches": launches,
+                 "flop_per_test": flop_per_test, "tests_per_launch": tests / max(1, launches),
+                 "both_filter_kernels_tflops": both / 1e12,
+                 "filter_ms_per_step": both_ms / args.steps,
+                 "reference_precision_kernels_ms_per_step": st["exact_ms"] / args.steps,
+                 "exact_retests_per_ray": st["exact_tests"] / max(1, rays_local),
+                 "nominal_tests_per_step": (st["closest_tests"] + st["anyhit_tests"]) / max(1, args.steps),
+                 "executed_reference_precision_tests_per_step": st["exact_tests"] / max(1, args.steps)}
+        roof = {"bound": "valu_fp32", "peak": PEAK_FP32_VALU / 1e12, "unit": "TFLOP/s",
+                "peak_from_device_properties": {"compute_units": n_cu, "clock_mhz": clock_khz / 1e3 if clock_khz else None,
+                                                "tflops": device_peak / 1e12 if device_peak else None},
+                "timing": "HIP events on the launch stream, K frames after the timed region with the library's two streams "
+                          "serialised (the default configuration takes %.2f ms per frame serialised)" % (serial_elapsed / args.steps * 1e3),
+                "traffic": None,
+                "default_scans": default_scans, "plain_scan": plain}
+        if executed is not None:
+            names = {"camera_rays": "k_filter<0, %d, form, 1> (camera rays)" % 8,
+                     "reflection_rays": "k_filter<0, %d, form, 4> (reflection rays)" % 4,
+                     "shadow_rays": "k_filter<1, %d, form, 2> (shadow rays)" % 8}
+            dom_scan = max(names, key=lambda k: executed[k]["ms_per_step"])
+            roof.update({"kernel": names[dom_scan] + ": the scan kernel of the timed configuration with the largest share of "
+                                                      "the frame; executed FP32 operations of its three stages (bundle judgement, "
+                                                      "per-ray bounding test, triangle test) over its duration",
+                         "achieved": executed[dom_scan]["executed_tflops"], "frac": executed[dom_scan]["frac_of_peak"],
+                         "timed_configuration": executed})
+        else:
+            roof.update({"kernel": plain["kernel"], "achieved": plain["achieved"], "frac": plain["frac"]})
+        line["roofline"] = roof
         if lbvh is not None:
             line["lbvh"] = lbvh
         if world == 1 and not args.no_cpu_baseline:

@@ -101,14 +101,40 @@ typedef enum rt_option {
     RT_OPT_OVERLAP = 7,      /* 1 (default): a level's shadow-ray launches run on an internal stream beside the
                                 next level's nearest-hit launches (joined back into the caller's stream before
                                 the call's last kernel); 0: one stream.  Off while RT_OPT_PROFILE is on */
-    RT_OPT_BOUNDING_TESTS = 8 /* 1 (default): the brute-force scan first asks whether any ray of a lane can reach
+    RT_OPT_BOUNDING_TESTS = 8, /* 1 (default): the brute-force scan first asks whether any ray of a lane can reach
                                 the triangle's bounding sphere and runs the triangle test only then: 2-3
                                 multiply-adds per ray where all rays of a launch pass through one point (camera
                                 rays: the eye; shadow rays: a point light) or are parallel (a directional
                                 light) -- these need RT_OPT_SHARED_CONSTANTS --, 12 for rays with nothing in
                                 common (reflection rays); 2: only the former; 0: every pair takes the triangle
                                 test.  Frames are identical in all three */
+    RT_OPT_WORK_COUNTERS = 9  /* 1: the brute-force scans count the work they execute (rt_stats.scan_work) in
+                                 instances of the scan kernels compiled for it; 0 (default): the scans carry no
+                                 counting code.  Frames are identical */
 } rt_option;
+
+/* Executed work of the brute-force scans of one kind of ray (RT_OPT_WORK_COUNTERS).  A scan hands
+ * out tasks (a block of 256 or 512 rays x a part of the triangle range); a task judges clusters
+ * of 64 triangles against what bounds its rays together, then the triangles of the clusters that
+ * pass (a "group": one triangle per lane), evaluates per-ray bounding tests for the batches of 4
+ * triangles that survive, and runs the FP32 triangle test where a lane asks for it. */
+typedef struct rt_scan_work {
+    uint64_t tasks;
+    uint64_t groups;            /* groups of 64 triangles judged */
+    uint64_t group_tests;       /* (bundle of rays, triangle) bounding questions asked in them */
+    uint64_t groups_live;       /* groups with a triangle that a bundle can reach */
+    uint64_t batches;           /* batches of 4 triangles whose per-ray bounding tests were evaluated */
+    uint64_t ray_bound_tests;   /* per-ray bounding tests executed (whole waves: 64 lanes x rays per lane x 4) */
+    uint64_t batches_tested;    /* batches in which some lane asked for a triangle test */
+    uint64_t tri_tests;         /* FP32 triangle tests executed (whole waves: 64 lanes x rays per lane) */
+    uint64_t tri_tests_wanted;  /* ... of which in lanes that had asked for the triangle */
+    uint64_t listed;            /* pairs listed for the reference-precision re-test */
+    uint64_t clusters;          /* clusters of 64 triangles judged, one level above the groups */
+} rt_scan_work;
+
+enum { RT_SCAN_PLAIN_NEAREST = 0,  /* nearest hit, every pair takes the triangle test */
+       RT_SCAN_CAMERA = 1, RT_SCAN_SHADOW_POINT = 2, RT_SCAN_SHADOW_DIRECTIONAL = 3, RT_SCAN_REFLECTION = 4,
+       RT_SCAN_PLAIN_SHADOW = 5, RT_SCAN_KINDS = 6 };
 
 /* Counters since rt_upload_scene or the last rt_reset_stats. */
 typedef struct rt_stats {
@@ -133,6 +159,10 @@ typedef struct rt_stats {
     double camera_ms;        /* RT_OPT_PROFILE: the part of closest_ms spent in launches of camera rays with
                                 RT_OPT_BOUNDING_TESTS on (the others scan rays that have nothing in common) */
     uint32_t camera_launches, reserved;
+    rt_scan_work scan_work[RT_SCAN_KINDS];   /* RT_OPT_WORK_COUNTERS */
+    double scan_ms[RT_SCAN_KINDS];           /* RT_OPT_PROFILE: summed duration of the scan launches by kind (a shadow
+                                                launch holds both kinds of light: booked under the kind of light 0) */
+    uint32_t scan_launches[RT_SCAN_KINDS];
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;

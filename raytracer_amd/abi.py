@@ -12,6 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 RT_OK, RT_ERR_ARG, RT_ERR_DEVICE, RT_ERR_RANGE, RT_ERR_STATE = 0, -1, -2, -3, -4
 RT_OPT_EXACT_ONLY, RT_OPT_PROFILE, RT_OPT_PASS_PIXELS, RT_OPT_USE_BVH, RT_OPT_FILTER_FORM, RT_OPT_SHARED_CONSTANTS, RT_OPT_OVERLAP = 1, 2, 3, 4, 5, 6, 7
 RT_OPT_BOUNDING_TESTS = 8
+RT_OPT_WORK_COUNTERS = 9
+SCAN_KINDS = ["plain_nearest", "camera", "shadow_point", "shadow_directional", "reflection", "plain_shadow"]
 
 
 class RtMaterial(C.Structure):
@@ -44,6 +46,11 @@ class RtSceneDesc(C.Structure):
     ]
 
 
+class RtScanWork(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("tasks", "groups", "group_tests", "groups_live", "batches", "ray_bound_tests",
+                                          "batches_tested", "tri_tests", "tri_tests_wanted", "listed", "clusters")]
+
+
 class RtStats(C.Structure):
     _fields_ = [
         ("rays_primary", C.c_uint64), ("rays_reflect", C.c_uint64), ("rays_shadow", C.c_uint64),
@@ -56,10 +63,16 @@ class RtStats(C.Structure):
         ("n_triangles", C.c_int32), ("n_spheres", C.c_int32), ("n_groups", C.c_int32),
         ("n_irregular", C.c_int32), ("filter_form", C.c_int32),
         ("camera_ms", C.c_double), ("camera_launches", C.c_uint32), ("reserved", C.c_uint32),
+        ("scan_work", RtScanWork * 6), ("scan_ms", C.c_double * 6), ("scan_launches", C.c_uint32 * 6),
     ]
 
     def as_dict(self):
-        return {name: getattr(self, name) for name, _ in self._fields_}
+        out = {name: getattr(self, name) for name, _ in self._fields_ if not name.startswith("scan_")}
+        out["scan_work"] = {kind: {n: getattr(self.scan_work[k], n) for n, _ in RtScanWork._fields_}
+                            for k, kind in enumerate(SCAN_KINDS)}
+        out["scan_ms"] = {kind: self.scan_ms[k] for k, kind in enumerate(SCAN_KINDS)}
+        out["scan_launches"] = {kind: self.scan_launches[k] for k, kind in enumerate(SCAN_KINDS)}
+        return out
 
 
 HOST_SYMBOLS = ["rth_load_scene", "rth_load_blob", "rth_save_blob", "rth_desc", "rth_free_scene",
@@ -77,7 +90,8 @@ def host_lib_path():
 
 
 def device_lib_path():
-    return os.path.join(_HERE, "libraytracer_amd.so")
+    # RAYTRACER_AMD_LIB: another build of the same library (A/B measurements of kernel variants)
+    return os.environ.get("RAYTRACER_AMD_LIB") or os.path.join(_HERE, "libraytracer_amd.so")
 
 
 def host_lib():

@@ -187,6 +187,8 @@ struct rt_ctx {
     DevBuf<uint32_t> own_frame;
     uint32_t* frame = nullptr;     // own_frame.p or the caller's buffer
     DevBuf<DevCounters> counters;
+    DevBuf<unsigned long long> work;   // [RT_WORK_KINDS][RT_WORK_FIELDS], see WorkCount
+    int work_counters = 0;             // RT_OPT_WORK_COUNTERS
 
     // workspace, sized for `ws.cap` rays per pass: one allocation, cut by carve_workspace
     Workspace ws;
@@ -213,6 +215,11 @@ struct rt_ctx {
     DevBuf<float> bound_lights;           // [n_lights][n_regular + 8][4]: bounding cone / disc of each triangle per light
     DevBuf<double> light_frame;           // [n_lights][8]: plane coordinates of a directional light
     DevBuf<float> sphere_any, plane_any;  // [n_regular + 8][4] each: bounding sphere / plane of each triangle (rays with nothing in common)
+    // the same one level up: clusters of 64 consecutive regular slots (see TraceArgs)
+    DevBuf<float> cl_camera, cl_lights, cl_sphere, cl_normal;
+    DevBuf<int32_t> graze_slots, graze_start;   // per light: the triangles a shadow ray can graze (see TraceArgs)
+    int n_clusters = 0;
+    int n_regular_real = 0;               // regular triangles without the copies that fill up the axis ranges
     int pretest_any = 1;                  // ... and whether those are used
     int pretest = 1;                      // bounding-volume tests in front of the FP32 triangle test
     std::vector<DevLight> h_lights;
@@ -240,8 +247,10 @@ struct rt_ctx {
     struct Span { hipEvent_t a, b; int kind; };
     std::vector<Span> spans;
     std::vector<hipEvent_t> event_pool;
-    double ms[4] = {0, 0, 0, 0};   // filter MODE 0 (rays with nothing in common), filter MODE 1, reference-precision kernels, filter MODE 0 of camera rays
-    unsigned launches[4] = {0, 0, 0, 0};
+    // summed durations (RT_OPT_PROFILE): [0 .. RT_WORK_KINDS) the scan launches by kind (see WorkCount; LBVH
+    // traversals are booked as kinds 0 and 5), [RT_WORK_KINDS] the reference-precision kernels
+    double ms[RT_WORK_KINDS + 1] = {};
+    unsigned launches[RT_WORK_KINDS + 1] = {};
 };
 
 namespace {
@@ -404,13 +413,25 @@ int launch_trace(rt_ctx* c, const Workspace& W, TraceArgs A, hipStream_t st, siz
     const bool light_bounds = MODE == 1 && c->shared_consts && c->pretest && c->bound_lights.n > 0;
     A.bound_lights = light_bounds ? c->bound_lights.p : nullptr;
     A.light_frame = light_bounds ? c->light_frame.p : nullptr;
+    A.cl_camera = c->cl_camera.p; A.cl_lights = c->cl_lights.p;
+    A.graze_slots = c->graze_slots.p; A.graze_start = c->graze_start.p;
+    if (MODE == 1 && light_bounds) A.plane_any = c->plane_any.p;
+    A.cl_sphere = c->cl_sphere.p; A.cl_normal = c->cl_normal.p; A.n_clusters = c->n_clusters;
     A.pair_count = (unsigned long long*)W.ray_flags[MODE];
     A.task_counter = (unsigned int*)(A.pair_count + 1);
     A.ray_flags = W.ray_flags[MODE] + 16; A.pairs = W.pairs[MODE];
     A.pair_cap = (unsigned int)W.pair_cap[MODE]; A.counters = c->counters.p; A.scan_all = c->force_exact;
+    const bool work = c->work_counters && c->work.p;
+    A.work = work ? c->work.p : nullptr;
     HIP_TRY(hipMemsetAsync(W.ray_flags[MODE], 0, std::min(W.ray_flags_n[MODE], max_rays + 16), st));   // (no queue of the pass is longer)
     if (!c->force_exact && c->hs.n_regular > 0) {
-        Timed t(c, st, (MODE == 0 && A.cone_camera && !c->use_bvh) ? 3 : MODE, events);
+        int scan_kind = MODE == 0 ? 0 : 5;
+        if (!c->use_bvh) {
+            if (MODE == 0 && A.cone_camera) scan_kind = 1;
+            else if (MODE == 0 && A.sphere_any) scan_kind = 4;
+            else if (MODE == 1 && A.bound_lights) scan_kind = (c->h_lights.empty() || c->h_lights[0].is_point) ? 2 : 3;
+        }
+        Timed t(c, st, scan_kind, events);
         if (c->use_bvh) {
             BvhArgs ba;
             ba.bvh = c->bvh_groups.p; ba.nodes = c->bvh_nodes.p; ba.filt = (const float*)c->tri_filt.p;
@@ -421,24 +442,26 @@ int launch_trace(rt_ctx* c, const Workspace& W, TraceArgs A, hipStream_t st, siz
         } else {
             const dim3 grid(c->filter_grid[MODE]), block(RT_BLOCK);
             const v16f* records = (const v16f*)c->tri_filt.p;
-            if (MODE == 0 && A.cone_camera) {
-                if (c->robust) hipLaunchKernelGGL((k_filter<0, RT_RPL_SHARED, true, 1>), grid, block, 0, st, dsc, records, A);
-                else hipLaunchKernelGGL((k_filter<0, RT_RPL_SHARED, false, 1>), grid, block, 0, st, dsc, records, A);
-            } else if (MODE == 0 && A.sphere_any) {
-                if (c->robust) hipLaunchKernelGGL((k_filter<0, RT_RPL_ANY, true, 4>), grid, block, 0, st, dsc, records, A);
-                else hipLaunchKernelGGL((k_filter<0, RT_RPL_ANY, false, 4>), grid, block, 0, st, dsc, records, A);
-            } else if (MODE == 1 && A.bound_lights) {
-                if (c->robust) hipLaunchKernelGGL((k_filter<1, RT_RPL_SHARED, true, 2>), grid, block, 0, st, dsc, records, A);
-                else hipLaunchKernelGGL((k_filter<1, RT_RPL_SHARED, false, 2>), grid, block, 0, st, dsc, records, A);
-            } else {
-                if (c->robust) hipLaunchKernelGGL((k_filter<MODE, RT_RPL, true, 0>), grid, block, 0, st, dsc, records, A);
-                else hipLaunchKernelGGL((k_filter<MODE, RT_RPL, false, 0>), grid, block, 0, st, dsc, records, A);
-            }
+#define RT_LAUNCH_FILTER(M, R, CN)                                                                                  \
+            do {                                                                                                    \
+                if (work) {                                                                                         \
+                    if (c->robust) hipLaunchKernelGGL((k_filter<M, R, true, CN, true>), grid, block, 0, st, dsc, records, A);  \
+                    else hipLaunchKernelGGL((k_filter<M, R, false, CN, true>), grid, block, 0, st, dsc, records, A); \
+                } else {                                                                                            \
+                    if (c->robust) hipLaunchKernelGGL((k_filter<M, R, true, CN, false>), grid, block, 0, st, dsc, records, A); \
+                    else hipLaunchKernelGGL((k_filter<M, R, false, CN, false>), grid, block, 0, st, dsc, records, A); \
+                }                                                                                                   \
+            } while (0)
+            if (MODE == 0 && A.cone_camera) RT_LAUNCH_FILTER(0, RT_RPL_SHARED, 1);
+            else if (MODE == 0 && A.sphere_any) RT_LAUNCH_FILTER(0, RT_RPL_ANY, 4);
+            else if (MODE == 1 && A.bound_lights) RT_LAUNCH_FILTER(1, RT_RPL_SHARED, 2);
+            else RT_LAUNCH_FILTER(MODE, RT_RPL, 0);
+#undef RT_LAUNCH_FILTER
         }
         HIP_TRY(hipGetLastError());
         t.stop();
     }
-    Timed t(c, st, 2, events);
+    Timed t(c, st, RT_WORK_KINDS, events);
     if (!c->force_exact && c->hs.n_regular > 0 && !c->use_bvh) {      // (the LBVH traversal lists no pairs)
         hipLaunchKernelGGL(k_exact_pairs<MODE>, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, dsc,
                            (const TriExact*)c->tri_exact.p, A);
@@ -679,6 +702,25 @@ int install_filter(rt_ctx* c, int robust) {
             if (regular(t)) order_reg[n_reg[(size_t)t.xf * 3 + t.axis]++] = k; else order_irr[n_irr[(size_t)t.xf]++] = k;
         }
     }
+    // Every (transform, axis) range starts at a multiple of 64 slots, so that clusters of 64 consecutive
+    // slots never straddle two ranges: the slots between a range's last triangle and the next multiple of
+    // 64 are holes (order_reg = -1).  No scan visits a hole (the ranges end at their last triangle); the
+    // kernels that walk whole groups (full reference-precision scan, LBVH) skip them by TriExact::hole.
+    c->n_regular_real = (int)order_reg.size();
+    std::vector<int> slot_xf, slot_axis;             // per slot, holes included
+    {
+        std::vector<int> padded;
+        padded.reserve(order_reg.size() + 192);
+        size_t r = 0;
+        while (r < order_reg.size()) {
+            const int x = tris[order_reg[r]].xf, a = tris[order_reg[r]].axis;
+            while (r < order_reg.size() && tris[order_reg[r]].xf == x && tris[order_reg[r]].axis == a) {
+                padded.push_back(order_reg[r++]); slot_xf.push_back(x); slot_axis.push_back(a);
+            }
+            while (padded.size() % 64) { padded.push_back(-1); slot_xf.push_back(x); slot_axis.push_back(a); }
+        }
+        order_reg.swap(padded);
+    }
     const int NR = (int)order_reg.size(), NI = (int)order_irr.size();
     const size_t parts = host_parts(tris.size());
     std::vector<v16f> filt((size_t)NR + 1);          // + one readable padding record
@@ -687,23 +729,31 @@ int install_filter(rt_ctx* c, int robust) {
     std::vector<int32_t>& slot = c->h_slot;
     parallel_ranges((size_t)NR, parts, [&](size_t, size_t k0, size_t k1) {
         for (size_t k = k0; k < k1; k++) {
+            if (order_reg[k] < 0) {
+                for (int j = 0; j < 16; j++) filt[k][j] = 0.f;
+                std::memset(&exact[k], 0, sizeof(TriExact));
+                exact[k].hole = 1; exact[k].obj = -1;
+                continue;
+            }
             const HostTri& t = tris[order_reg[k]];
             const float* f = robust ? t.f_robust : t.f_static;
             for (int j = 0; j < 16; j++) filt[k][j] = f[j];
             exact[k] = t.ex;
+            exact[k].hole = 0;
             slot[t.ex.obj] = (int32_t)k;
         }
     });
     for (int k = 0; k < NI; k++) {
         const HostTri& t = tris[order_irr[k]];
         exact[(size_t)NR + k] = t.ex;
+        exact[(size_t)NR + k].hole = 0;
         slot[t.ex.obj] = NR + k;
     }
     std::vector<Group> groups;
     {
         int r = 0, q = 0;
         while (r < NR || q < NI) {
-            int xr = r < NR ? tris[order_reg[r]].xf : INT32_MAX;
+            int xr = r < NR ? slot_xf[r] : INT32_MAX;
             int xq = q < NI ? tris[order_irr[q]].xf : INT32_MAX;
             int x = std::min(xr, xq);
             Group G{};
@@ -711,7 +761,8 @@ int install_filter(rt_ctx* c, int robust) {
             G.q[0] = c->h_q0[x]; G.q[1] = c->h_q1[x];
             for (int a = 0; a < 3; a++) {
                 G.fax[a] = r;
-                while (r < NR && tris[order_reg[r]].xf == x && tris[order_reg[r]].axis == a) r++;
+                G.fcnt[a] = 0;
+                while (r < NR && slot_xf[r] == x && slot_axis[r] == a) { if (order_reg[r] >= 0) G.fcnt[a]++; r++; }
             }
             G.fax[3] = r;
             G.ibeg = NR + q;
@@ -730,6 +781,7 @@ int install_filter(rt_ctx* c, int robust) {
         for (int a = 0; a < 3; a++) { bx[a] = FLT_MAX; bx[3 + a] = -FLT_MAX; }
         for (int k2 = groups[gi].fax[0]; k2 < groups[gi].fax[3]; k2++) {
             const TriExact& ex = exact[k2];
+            if (ex.hole) continue;
             for (int a = 0; a < 3; a++) {
                 float cc = (float)(ex.v1[a] + (ex.e1[a] + ex.e2[a]) * (1.0 / 3.0));
                 bx[a] = std::min(bx[a], cc); bx[3 + a] = std::max(bx[3 + a], cc);
@@ -873,6 +925,134 @@ int install_filter(rt_ctx* c, int robust) {
                 }
             });
         }
+        // ---- one level up: clusters of 64 consecutive slots ----
+        {
+            const size_t NC = (size_t)NR / 64, NL = c->h_lights.size();
+            c->n_clusters = (int)NC;
+            std::vector<float> cl_sphere(4 * (NC + 1), 0.f), cl_normal(4 * (NC + 1), 0.f), cl_cam(4 * (NC + 1), 0.f);
+            std::vector<float> cl_lights(std::max<size_t>(NL, 1) * (NC + 1) * 4, 0.f);
+            std::vector<int32_t> graze_slots, graze_start(std::max<size_t>(NL, 1) * (NC + 1), 0);
+            std::vector<double> csph(4 * (NC + 1), 0.0);
+            // which group a cluster belongs to (for the eye in that group's space)
+            std::vector<int> cl_group(NC + 1, 0);
+            for (size_t gi = 0; gi < groups.size(); gi++)
+                for (int k = groups[gi].fax[0] / 64; k < groups[gi].fax[3] / 64; k++) cl_group[(size_t)k] = (int)gi;
+            parallel_ranges(NC, host_parts(NC * 64), [&](size_t, size_t c0, size_t c1) {
+                for (size_t cl = c0; cl < c1; cl++) {
+                    // sphere: centre = mean of the members' centres, radius = what holds every member's sphere
+                    double mx = 0, my = 0, mz = 0, nx = 0, ny = 0, nz = 0;
+                    for (size_t k = 64 * cl; k < 64 * cl + 64; k++) {
+                        if (exact[k].hole) continue;
+                        mx += sphere[4 * k]; my += sphere[4 * k + 1]; mz += sphere[4 * k + 2];
+                        nx += filt[k][0]; ny += filt[k][1]; nz += filt[k][2];
+                    }
+                    int members = 0;
+                    for (size_t k = 64 * cl; k < 64 * cl + 64; k++) members += exact[k].hole ? 0 : 1;
+                    mx /= members; my /= members; mz /= members;             // (a cluster holds at least one triangle)
+                    double rad = 0;
+                    for (size_t k = 64 * cl; k < 64 * cl + 64; k++) {
+                        if (exact[k].hole) continue;
+                        const double dx = sphere[4 * k] - mx, dy = sphere[4 * k + 1] - my, dz = sphere[4 * k + 2] - mz;
+                        // (the radius of the triangle-level test carries the rounding slack of its expanded form)
+                        const double rk = std::sqrt((double)sphere_any[4 * k + 3] + (double)sphere_any[4 * k] * sphere_any[4 * k] +
+                                                    (double)sphere_any[4 * k + 1] * sphere_any[4 * k + 1] +
+                                                    (double)sphere_any[4 * k + 2] * sphere_any[4 * k + 2]);
+                        rad = std::max(rad, std::sqrt(dx * dx + dy * dy + dz * dz) + std::max(sphere[4 * k + 3], rk));
+                    }
+                    rad = rad * (1 + 1e-5) + sphere_pad;
+                    const bool fin = std::isfinite(mx) && std::isfinite(my) && std::isfinite(mz) && std::isfinite(rad);
+                    csph[4 * cl] = fin ? mx : 0; csph[4 * cl + 1] = fin ? my : 0; csph[4 * cl + 2] = fin ? mz : 0;
+                    csph[4 * cl + 3] = fin ? rad : INFINITY;
+                    for (int q = 0; q < 4; q++) cl_sphere[4 * cl + q] = (float)csph[4 * cl + q];
+                    if (std::isfinite(cl_sphere[4 * cl + 3])) cl_sphere[4 * cl + 3] *= 1.0f + 1e-6f;
+                    // normal cone: mean normal and the sine of the largest angle a member's normal makes with it
+                    const double nl = std::sqrt(nx * nx + ny * ny + nz * nz);
+                    double sd = 1.0;
+                    if (nl > 1e-6 && std::isfinite(nl)) {
+                        nx /= nl; ny /= nl; nz /= nl;
+                        double cmin = 1.0;
+                        for (size_t k = 64 * cl; k < 64 * cl + 64; k++) {
+                        if (exact[k].hole) continue;
+                            const double len = std::sqrt((double)filt[k][0] * filt[k][0] + (double)filt[k][1] * filt[k][1] + (double)filt[k][2] * filt[k][2]);
+                            cmin = std::min(cmin, (filt[k][0] * nx + filt[k][1] * ny + filt[k][2] * nz) / len);
+                        }
+                        sd = cmin > 0 ? std::sqrt(std::max(0.0, 1.0 - cmin * cmin)) + 1e-5 : 1.0;
+                        if (!std::isfinite(sd)) sd = 1.0;
+                    } else { nx = 0; ny = 0; nz = 1; }
+                    cl_normal[4 * cl] = (float)nx; cl_normal[4 * cl + 1] = (float)ny; cl_normal[4 * cl + 2] = (float)nz;
+                    cl_normal[4 * cl + 3] = (float)std::min(1.0, sd);
+                    // camera rays: the cone from the eye (in the group's space); "every direction" when the eye
+                    // lies in a member's plane (the in-plane-origin case ignores where the triangle is)
+                    const Group& G = groups[(size_t)cl_group[cl]];
+                    const Vec o = G.identity ? eye : affine_point(&c->h_xf[48 * (size_t)G.xf + 16], eye);
+                    bounding_cone(o, {csph[4 * cl], csph[4 * cl + 1], csph[4 * cl + 2]}, csph[4 * cl + 3], &cl_cam[4 * cl]);
+                    for (size_t k = 64 * cl; k < 64 * cl + 64; k++)
+                        if (!exact[k].hole && !(std::fabs(eye_a[k]) > G.q[0].a_zero)) cl_cam[4 * cl + 3] = -2.f;
+                }
+            });
+            cl_cam[4 * NC + 3] = -2.f;
+            const double half = c->scene_bound;
+            for (size_t l = 0; l < NL; l++) {
+                const DevLight& lt = c->h_lights[l];
+                float* B = &cl_lights[l * (NC + 1) * 4];
+                int32_t* GS = &graze_start[l * (NC + 1)];
+                const Vec Lp{lt.pos[0], lt.pos[1], lt.pos[2]};
+                const double x = -lt.pos[0], y = -lt.pos[1], z = -lt.pos[2];
+                const double len = std::sqrt(x * x + y * y + z * z), inv = 1. / len;
+                const Vec dir{x * inv, y * inv, z * inv};
+                // the light's plane coordinates as the per-triangle table has them
+                Vec e1{0, 0, 0}, e2{0, 0, 0};
+                bool usable = false;
+                if (!lt.is_point) {
+                    Vec t = std::fabs(dir.x) <= std::fabs(dir.y) && std::fabs(dir.x) <= std::fabs(dir.z) ? Vec{1, 0, 0}
+                          : (std::fabs(dir.y) <= std::fabs(dir.z) ? Vec{0, 1, 0} : Vec{0, 0, 1});
+                    e1 = vcross(dir, t);
+                    const double l1 = vlen(e1);
+                    e1 = {e1.x / l1, e1.y / l1, e1.z / l1};
+                    e2 = vcross(dir, e1);
+                    usable = std::isfinite(e1.x) && std::isfinite(e1.y) && std::isfinite(e1.z) && std::isfinite(e2.x) &&
+                             std::isfinite(e2.y) && std::isfinite(e2.z);
+                }
+                const double rmax = half * (1 + 1e-3);
+                const double slack = 16.0 * 1.1920928955078125e-7 * rmax * rmax;
+                const double l1norm = std::fabs(Lp.x) + std::fabs(Lp.y) + std::fabs(Lp.z);
+                for (size_t cl = 0; cl < NC; cl++) {
+                    const Vec ctr{csph[4 * cl], csph[4 * cl + 1], csph[4 * cl + 2]};
+                    const double rho = csph[4 * cl + 3];
+                    // Graze list: what the plane guard of any task could name.  Its limit is b_hi * (largest distance
+                    // from the task's origins to the light) + 2 a_zero + rounding for a point light -- origins lie
+                    // within the scene's bound of the origin of coordinates --, b_hi for a directional light; the
+                    // kernel evaluates the same quantities in FP32, whose rounding is allowed for here.
+                    GS[cl] = (int32_t)graze_slots.size();
+                    for (size_t k = 64 * cl; k < 64 * cl + 64; k++) {
+                        if (exact[k].hole) continue;
+                        const double nxk = filt[k][0], nyk = filt[k][1], nzk = filt[k][2], d0 = filt[k][3];
+                        const double o = lt.is_point ? std::fabs(d0 - (nxk * Lp.x + nyk * Lp.y + nzk * Lp.z))
+                                                     : std::fabs(nxk * dir.x + nyk * dir.y + nzk * dir.z);
+                        const GroupFilter& q1 = c->h_q1[0];       // (shadow thresholds are the same for every transform)
+                        const double far = std::sqrt(3.0) * half + vlen(Lp);
+                        const double limit = lt.is_point ? (double)q1.b_hi * far * (1 + 1e-3) + 2.0 * q1.a_zero + 1e-5 * (l1norm + half) + 1e-6
+                                                         : (double)q1.b_hi * (1 + 2e-3) + 1e-5;
+                        if (!(o > limit)) graze_slots.push_back((int32_t)k);
+                    }
+                    if (lt.is_point) {
+                        bounding_cone(Lp, ctr, rho, &B[4 * cl]);
+                    } else {
+                        const double cu = vdot(ctr, e1), cv = vdot(ctr, e2);
+                        double kk = rho * rho + 3.0 * 1.1920928955078125e-7 * rho * rmax - cu * cu - cv * cv + slack;
+                        if (!usable || !std::isfinite(kk)) kk = INFINITY;
+                        B[4 * cl] = (float)(-2.0 * cu); B[4 * cl + 1] = (float)(-2.0 * cv);
+                        B[4 * cl + 2] = (kk == INFINITY) ? INFINITY : (float)kk + std::fabs((float)kk) * 1e-6f;
+                        B[4 * cl + 3] = 0.f;
+                        if (!std::isfinite(B[4 * cl]) || !std::isfinite(B[4 * cl + 1])) { B[4 * cl] = B[4 * cl + 1] = 0.f; B[4 * cl + 2] = INFINITY; }
+                    }
+                }
+            }
+            HIP_TRY(c->cl_sphere.upload(cl_sphere)); HIP_TRY(c->cl_normal.upload(cl_normal)); HIP_TRY(c->cl_camera.upload(cl_cam));
+            for (size_t l = 0; l < NL; l++) graze_start[l * (NC + 1) + NC] = (int32_t)((l + 1 < NL) ? graze_start[(l + 1) * (NC + 1)] : (int32_t)graze_slots.size());
+            graze_slots.push_back(0);                        // (never empty)
+            HIP_TRY(c->cl_lights.upload(cl_lights)); HIP_TRY(c->graze_slots.upload(graze_slots)); HIP_TRY(c->graze_start.upload(graze_start));
+        }
         HIP_TRY(c->eye_a.upload(eye_a));
         HIP_TRY(c->cone_camera.upload(cone_cam));
         HIP_TRY(c->sphere_any.upload(sphere_any)); HIP_TRY(c->plane_any.upload(plane_any));
@@ -885,6 +1065,7 @@ int install_filter(rt_ctx* c, int robust) {
     DevScene& s = c->hs;
     s.tri_filt = c->tri_filt.p; s.tri_exact = c->tri_exact.p; s.groups = c->groups.p; s.obj_slot = c->obj_slot.p;
     s.n_regular = NR; s.n_irregular = NI; s.n_groups = (int)groups.size();
+    s.n_prims_nominal = c->n_regular_real + NI + s.n_spheres;
     s.robust_filter = robust ? 1 : 0;
     std::vector<DevScene> one(1, s);
     HIP_TRY(c->d_scene.upload(one));
@@ -1293,6 +1474,8 @@ static int upload_scene(rt_ctx** out, const rt_scene_desc* d) {
     e = hipMemset(c->frame, 0, (size_t)d->width * d->height * 4);
     if (e == hipSuccess) e = c->counters.alloc(1);
     if (e == hipSuccess) e = hipMemset(c->counters.p, 0, sizeof(DevCounters));
+    if (e == hipSuccess) e = c->work.alloc(RT_WORK_KINDS * RT_WORK_FIELDS);
+    if (e == hipSuccess) e = hipMemset(c->work.p, 0, RT_WORK_KINDS * RT_WORK_FIELDS * sizeof(unsigned long long));
     if (e != hipSuccess) return bail(fail(RT_ERR_DEVICE, std::string("init: ") + hipGetErrorString(e)));
 
     // launch geometry: as many resident blocks as the filter kernels admit
@@ -1335,6 +1518,7 @@ int rt_set_option(rt_ctx* c, int option, int64_t value) {
         }
         case RT_OPT_SHARED_CONSTANTS: c->shared_consts = value ? 1 : 0; return 0;
         case RT_OPT_OVERLAP: c->overlap = value ? 1 : 0; return 0;
+        case RT_OPT_WORK_COUNTERS: c->work_counters = value ? 1 : 0; return 0;
         case RT_OPT_BOUNDING_TESTS: c->pretest = value ? 1 : 0; c->pretest_any = value == 1 ? 1 : 0; return 0;
         case RT_OPT_USE_BVH:
             if (value) {
@@ -1485,11 +1669,15 @@ int rt_get_stats(rt_ctx* c, rt_stats* out) {
     out->exact_tests = dc.exact_tests;
     out->bvh_node_tests = dc.bvh_node_tests; out->bvh_leaf_tests = dc.bvh_leaf_tests;
     out->in_plane_origin_hits = dc.in_plane_origin_hits; out->flagged_rays = dc.flagged_rays;
-    out->closest_ms = c->ms[0] + c->ms[3]; out->anyhit_ms = c->ms[1];
-    out->closest_launches = c->launches[0] + c->launches[3]; out->anyhit_launches = c->launches[1];
-    out->camera_ms = c->ms[3]; out->camera_launches = c->launches[3]; out->reserved = 0;
-    out->exact_ms = c->ms[2]; out->exact_launches = c->launches[2];
-    out->n_triangles = c->hs.n_regular + c->hs.n_irregular; out->n_spheres = c->hs.n_spheres;
+    out->closest_ms = c->ms[0] + c->ms[1] + c->ms[4]; out->anyhit_ms = c->ms[2] + c->ms[3] + c->ms[5];
+    out->closest_launches = c->launches[0] + c->launches[1] + c->launches[4];
+    out->anyhit_launches = c->launches[2] + c->launches[3] + c->launches[5];
+    out->camera_ms = c->ms[1]; out->camera_launches = c->launches[1]; out->reserved = 0;
+    out->exact_ms = c->ms[RT_WORK_KINDS]; out->exact_launches = c->launches[RT_WORK_KINDS];
+    static_assert(RT_WORK_KINDS == RT_SCAN_KINDS && sizeof(rt_scan_work) == RT_WORK_FIELDS * sizeof(uint64_t), "scan work layout");
+    HIP_TRY(hipMemcpy(out->scan_work, c->work.p, sizeof out->scan_work, hipMemcpyDeviceToHost));
+    for (int k = 0; k < RT_SCAN_KINDS; k++) { out->scan_ms[k] = c->ms[k]; out->scan_launches[k] = c->launches[k]; }
+    out->n_triangles = c->n_regular_real + c->hs.n_irregular; out->n_spheres = c->hs.n_spheres;
     out->n_groups = c->hs.n_groups; out->n_irregular = c->hs.n_irregular;
     out->filter_form = c->robust ? 2 : 1;
     return 0;
@@ -1500,8 +1688,9 @@ int rt_reset_stats(rt_ctx* c) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->last_stream));
     drain_spans(c);
-    for (int k = 0; k < 4; k++) { c->ms[k] = 0; c->launches[k] = 0; }
+    for (int k = 0; k <= RT_WORK_KINDS; k++) { c->ms[k] = 0; c->launches[k] = 0; }
     HIP_TRY(hipMemset(c->counters.p, 0, sizeof(DevCounters)));
+    HIP_TRY(hipMemset(c->work.p, 0, RT_WORK_KINDS * RT_WORK_FIELDS * sizeof(unsigned long long)));
     return 0;
 }
 
@@ -1522,7 +1711,7 @@ void rt_free(rt_ctx* c) {
     c->xforms.release(); c->xf_identity.release(); c->obj_kind.release(); c->obj_slot.release();
     c->obj_material.release(); c->obj_transform.release(); c->obj_interp.release(); c->obj_geom.release();
     c->obj_normals.release(); c->materials.release(); c->lights.release(); c->own_frame.release();
-    c->counters.release();
+    c->counters.release(); c->work.release();
     c->ws_block.release();
     for (auto e : c->ev_hit) (void)hipEventDestroy(e);
     for (auto e : c->ev_phong) (void)hipEventDestroy(e);
@@ -1530,6 +1719,8 @@ void rt_free(rt_ctx* c) {
     c->bvh_nodes.release(); c->bvh_groups.release(); c->bvh_spill.release();
     c->eye_a.release(); c->dir_rinv.release(); c->light_dir_row.release(); c->cone_camera.release();
     c->bound_lights.release(); c->light_frame.release(); c->sphere_any.release(); c->plane_any.release();
+    c->cl_camera.release(); c->cl_lights.release(); c->cl_sphere.release(); c->cl_normal.release();
+    c->graze_slots.release(); c->graze_start.release();
     delete c;
 }
 

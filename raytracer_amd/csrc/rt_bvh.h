@@ -23,6 +23,7 @@
 #define RT_BVH_SPILL 48         // ... and deeper ones in a per-thread strip of global memory
 #define RT_BVH_STAGE 4          // per-lane staged candidates (LDS)
 #define RT_BVH_STEPS 8          // traversal steps between two drain phases
+#define RT_BVH_NO_CHILD (-2147483647 - 1)   // child code of a leaf whose slot holds no triangle (TriExact::hole): never entered
 
 struct __attribute__((aligned(16))) BvhNode {
     float lo[2][3], hi[2][3];   // boxes of the two children
@@ -128,8 +129,11 @@ __global__ void k_bvh_refit(const TriExact* __restrict__ exact, const int* __res
         double p0 = T.v1[a], p1 = T.v1[a] + T.e1[a], p2 = T.v1[a] + T.e2[a];
         lo[a] = round_down(fmin(p0, fmin(p1, p2))) - pad;
         hi[a] = round_up(fmax(p0, fmax(p1, p2))) + pad;
+        // a hole in the slot range (see TriExact::hole) adds nothing to the boxes above it
+        if (T.hole) { lo[a] = 3.0e38f; hi[a] = -3.0e38f; }
     }
     int link = parent_of_leaf[k];
+    if (T.hole && link >= 0) nodes[link >> 1].child[link & 1] = RT_BVH_NO_CHILD;     // (k_bvh_hierarchy has finished: a launch earlier)
     while (link >= 0) {
         const int node = link >> 1, side = link & 1;
         for (int a = 0; a < 3; a++) {
@@ -311,7 +315,7 @@ k_bvh_trace(const DevScene* __restrict__ sc, BvhArgs B, TraceArgs A) {
                     // leaf: the FP32 triangle filter; survivors wait in the stage for the drain phase
                     if (n_staged == RT_BVH_STAGE) break;
                     const int slot = -1 - cur;
-                    const int axis = slot >= G->fax[2] ? 2 : (slot >= G->fax[1] ? 1 : 0);
+                    const int axis = slot >= G->fax[2] ? 2 : (slot >= G->fax[1] ? 1 : 0);     // (fax[k]: where axis k's slots begin)
                     n_leaf++;
                     float r_lo;
                     if (filter_keep1(filt + 16 * (size_t)slot, axis, px, py, pz, vx, vy, vz, G->q[MODE], robust, MODE, &r_lo) &&
@@ -326,8 +330,8 @@ k_bvh_trace(const DevScene* __restrict__ sc, BvhArgs B, TraceArgs A) {
                 const BvhNode& N = nodes[cur];
                 n_node += 2;
                 float tn0, tn1;
-                const bool h0 = ray_reaches_box(N.lo[0], N.hi[0], px, py, pz, ix, iy, iz, &tn0) && !(tn0 > t_limit);
-                const bool h1 = ray_reaches_box(N.lo[1], N.hi[1], px, py, pz, ix, iy, iz, &tn1) && !(tn1 > t_limit);
+                const bool h0 = N.child[0] != RT_BVH_NO_CHILD && ray_reaches_box(N.lo[0], N.hi[0], px, py, pz, ix, iy, iz, &tn0) && !(tn0 > t_limit);
+                const bool h1 = N.child[1] != RT_BVH_NO_CHILD && ray_reaches_box(N.lo[1], N.hi[1], px, py, pz, ix, iy, iz, &tn1) && !(tn1 > t_limit);
                 if (h0 && h1) {
                     const int near = tn1 < tn0 ? 1 : 0;
                     if (sp == RT_BVH_STACK + RT_BVH_SPILL) { bail = true; active = false; break; }

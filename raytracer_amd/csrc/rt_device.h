@@ -27,7 +27,7 @@ struct __attribute__((aligned(16))) TriExact {
     int32_t obj;       // index in Scene::objects
     int32_t grp;       // index of the transform group
     float box_pad;     // how far outside the triangle the reference's own rounding can accept a point
-    int32_t pad;
+    int32_t hole;      // 1: no triangle here (a slot between the end of an axis range and the next multiple of 64)
 };
 
 struct __attribute__((aligned(16))) SphereRec {
@@ -56,7 +56,10 @@ struct GroupFilter {
 // are always tested in reference precision.
 struct Group {
     int32_t xf, identity;
-    int32_t fax[4];    // filter slots [fax[k], fax[k+1]): triangles whose normal's dominant axis is k
+    int32_t fax[4];    // filter slots from fax[k] on: triangles whose normal's dominant axis is k; every fax[k] is a
+                       // multiple of 64, [fax[0], fax[3]) is the group's whole slot range (holes included)
+    int32_t fcnt[3];   // ... and how many: the range of axis k is [fax[k], fax[k] + fcnt[k]); holes up to fax[k + 1]
+    int32_t pad;
     int32_t ibeg, iend;
     GroupFilter q[2];  // [0] nearest hit: rays in the group's object space (Scene::eps);
                        // [1] shadow: world-space rays against the untransformed vertices (0.1f)
@@ -83,7 +86,8 @@ struct DevScene {
     const DevLight* lights;
     int32_t n_regular, n_irregular, n_spheres, n_groups;
     int32_t n_objects, n_lights, n_transforms, last_xf;
-    int32_t width, height, max_depth, pad0;
+    int32_t width, height, max_depth;
+    int32_t n_prims_nominal;     // primitives of the scene (the copies that fill up the axis ranges not counted)
     float eps, shadow_eps;
     int32_t robust_filter;       // 1: filter records carry per-test margins (see filter_z2)
     int32_t pad1;

@@ -170,7 +170,43 @@ struct TraceArgs {
     // MODE 0, rays with nothing in common (null = no bounding test):
     const float* sphere_any;             // [n_regular + 8][4]  bounding sphere: centre, rho^2 - |centre|^2 (+ rounding slack)
     const float* plane_any;              // [n_regular + 8][4]  the triangle's plane (n, d0), a compact copy of the filter record's head
+    // One level up: the regular triangles in clusters of 64 consecutive slots (every axis range of every
+    // group starts at a multiple of 64), one record per cluster in the layout of the per-triangle table of
+    // the same kind, around the smallest sphere found around the cluster's bounding spheres.
+    const float* cl_camera;              // [n_clusters + 1][4]   like cone_camera
+    const float* cl_lights;              // [n_lights][n_clusters + 1][4]   like bound_lights
+    // Per light, the slots of the triangles whose plane a shadow ray towards that light can graze at all
+    // (in ascending order): the light lies close to the plane (point light) or nearly in it (directional
+    // light).  Only these can take the in-plane-origin branch of Triangle::intersection (raytracer.cpp:319).
+    const int32_t* graze_slots;          // all lights' lists, one after the other
+    const int32_t* graze_start;          // [n_lights][n_clusters + 1]: first entry of the light's list with slot >= 64 * cluster (index into graze_slots)
+    const float* cl_sphere;              // [n_clusters + 1][4]   centre, radius
+    const float* cl_normal;              // [n_clusters + 1][4]   unit mean normal N, sine of the largest angle between N and a member's normal
+    int32_t n_clusters;
+    unsigned long long* work;            // k_filter<..., WORK = true>: [RT_WORK_KINDS][RT_WORK_FIELDS] executed-work counters
 };
+
+// Executed work of the scans, counted per wave in registers and added to TraceArgs::work at the
+// end of every task (only in the WORK instances of k_filter; the others carry none of this).
+// Kinds of scan: 0 nearest hit without bounding tests, 1 camera rays, 2 shadow rays towards a
+// point light, 3 towards a directional light, 4 reflection rays, 5 shadow rays without
+// bounding tests.
+#define RT_WORK_KINDS 6
+#define RT_WORK_FIELDS 11
+enum {
+    RT_WK_TASKS = 0,        // tasks (block of rays x part of the triangle range)
+    RT_WK_GROUPS,           // groups of 64 triangles judged against the task's bundle(s) of rays
+    RT_WK_GROUP_TESTS,      // ... (bundle, triangle) questions asked in them: one per lane with a triangle and per bundle
+    RT_WK_GROUPS_LIVE,      // groups with a triangle some bundle can reach (or the plane guard names)
+    RT_WK_BATCHES,          // batches of 4 triangles whose per-ray bounding tests were evaluated
+    RT_WK_RAY_BOUND_TESTS,  // per-ray bounding tests executed in them (64 lanes x rays of the lane that took part x 4)
+    RT_WK_BATCHES_TESTED,   // batches in which some lane asked for a triangle test
+    RT_WK_TRI_TESTS,        // FP32 triangle tests executed: (wave, triangle) executions x 64 lanes x rays per lane
+    RT_WK_TRI_WANTED,       // ... of which in lanes that had asked for the triangle (all of them without bounding tests)
+    RT_WK_LISTED,           // pairs listed for the reference-precision re-test
+    RT_WK_CLUSTERS          // clusters of 64 triangles judged (one lane each, one level above the groups)
+};
+struct WorkCount { unsigned int v[RT_WORK_FIELDS]; };
 
 // Shadow rays are numbered light-major: ray = light * n_hits + hit, so that rays towards one
 // light are neighbours (a block of rays towards a directional light shares its direction).
@@ -388,18 +424,17 @@ __device__ __forceinline__ unsigned long long wave_append(unsigned long long* co
 
 // Appends the lane's staged candidates (LDS) to the pair list.
 template <int RPL>
-__device__ __forceinline__ void flush_candidates(const TraceArgs& A, const unsigned short* my_cand, int n_cand, int cbeg,
-                                                 unsigned int ray0, unsigned int n_rays, int lane) {
+__device__ __forceinline__ int flush_candidates(const TraceArgs& A, const unsigned short* my_cand, int n_cand, int cbeg,
+                                                unsigned int ray0, unsigned int n_rays, int lane) {
     constexpr int SLOT_SHIFT = RT_SLOT_SHIFT(RPL);
-    // inclusive prefix sum of n_cand over the wave
-    int incl = n_cand;
-    for (int off = 1; off < RT_WAVE; off <<= 1) {
-        int up = __shfl_up(incl, off);
-        if (lane >= off) incl += up;
-    }
-    const int total = __shfl(incl, RT_WAVE - 1);
+    // The list is written round by round: round k holds the k-th candidate of every lane that has one.
+    // Neighbouring lanes hold neighbouring rays, which tend to keep the same triangles in the same order,
+    // so neighbouring entries of the list name the same triangle and consecutive rays: the re-test kernel,
+    // one thread per entry, then fetches one triangle record and a run of consecutive rays per few lanes
+    // instead of one record and one ray from anywhere per lane.
+    int total = n_cand, most = n_cand;
+    for (int off = 32; off > 0; off >>= 1) { total += __shfl_xor(total, off); most = max(most, __shfl_xor(most, off)); }
     const unsigned long long base = wave_append(A.pair_count, (unsigned int)total, lane);
-    const unsigned long long first = base + (unsigned int)(incl - n_cand);
     if (base + (unsigned int)total > A.pair_cap) {
         // List full: every ray of this lane that has a candidate gets the full scan instead.
         // Entries that still fit are written all the same (they are valid pairs), so the list
@@ -410,13 +445,20 @@ __device__ __forceinline__ void flush_candidates(const TraceArgs& A, const unsig
             if (ray < n_rays && n_cand > 0) A.ray_flags[ray] = 1;
         }
     }
-    for (int k = 0; k < n_cand; k++) {
-        if (first + k >= A.pair_cap) break;
-        const unsigned int e = my_cand[k * RT_BLOCK];
-        const unsigned int r = e >> SLOT_SHIFT;
-        const unsigned int slot = (unsigned int)cbeg + (e & ((1u << SLOT_SHIFT) - 1u));
-        A.pairs[first + k] = ((unsigned long long)(ray0 + r * RT_WAVE) << 32) | slot;
+    unsigned long long at = base;
+    for (int k = 0; k < most; k++) {
+        const bool have = k < n_cand;
+        const unsigned long long holders = __ballot(have);
+        const unsigned long long mine = at + (unsigned int)__popcll(holders & ((1ull << lane) - 1ull));
+        if (have && mine < A.pair_cap) {
+            const unsigned int e = my_cand[k * RT_BLOCK];
+            const unsigned int r = e >> SLOT_SHIFT;
+            const unsigned int slot = (unsigned int)cbeg + (e & ((1u << SLOT_SHIFT) - 1u));
+            A.pairs[mine] = ((unsigned long long)(ray0 + r * RT_WAVE) << 32) | slot;
+        }
+        at += (unsigned int)__popcll(holders);
     }
+    return total;
 }
 
 // Filter loop over the regular triangles [abeg, aend) whose normals share the dominant axis AXIS.
@@ -486,22 +528,31 @@ struct PlaneGuard {
     // sine of its half-angle; PRE 3: a disc of origins in the light's plane -- centre in (bx, by), radius
     // in bcos).  cull = 0: no such bound (directions too far apart, or not finite).
     const float* bounds;                 // the table `cone` points to, as plain memory
+    const float* cl_bounds;              // the clusters' table of the same kind (PRE 4: their spheres)
+    const float* cl_normals;             // PRE 4: the clusters' normal cones
+    const int32_t* graze_slots;          // PRE 2, 3: see TraceArgs
+    const int32_t* graze_start;          // ... the light's row
     float bx, by, bz, bcos, bsin;
     int cull;
     // PRE 1, 2: rays of one scanline fan out in (nearly) one plane through the shared point: unit
     // normal of that plane (zero: no such plane), sine and cosine of the largest angle a ray makes with it
     float fx, fy, fz, fsin, fcos;
-    // PRE 4: one bundle per pair of ray slots (128 consecutive rays of the queue): ball of origins (centre,
-    // radius) and cone of directions (unit axis, cosine and sine of the half-angle); on = 0: no bound
-    float qm[4][4], qa[4][5];
-    int qon[4];
+    // PRE 4: two bundles per pair of ray slots (128 consecutive rays of the queue, split in two by
+    // direction when they do not run together), bundle 2q + c of pair q: the origins -- centre, radius about
+    // the bundle's axis line (see filter_range), radius of the ball around the centre -- and the cone of
+    // directions (unit axis, cosine and sine of the half-angle); qgraze: largest |n . axis-direction| at which a
+    // plane with unit normal n still holds a direction the reference calls grazing (raytracer.cpp:319).
+    // on = 1: bounds hold; 0: no bound (everything is in reach); -1: the bundle has no ray
+    float qm[8][5], qa[8][5], qgraze[8];
+    int qon[8];
 };
 
-template <int MODE, int RPL, int AXIS, bool ROBUST, int SHARED, int PRE>
+template <int MODE, int RPL, int AXIS, bool ROBUST, int SHARED, int PRE, bool WORK>
 __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* shared, const cv4f* cone,
                                              const PlaneGuard& guard, const TraceArgs& A,
                                              const FilterLane<RPL>& L, const FilterQuery fp, int abeg, int aend,
-                                             unsigned short* my_cand, unsigned int ray0, unsigned int n_rays, int lane) {
+                                             unsigned short* my_cand, unsigned int ray0, unsigned int n_rays, int lane,
+                                             WorkCount& wk) {
     constexpr int SLOT_SHIFT = RT_SLOT_SHIFT(RPL);
     // (with a bounding test: at most 64 groups of 64 triangles, one lane per group's masks)
     constexpr int CHUNK = (PRE && SLOT_SHIFT > 12) ? 4096 : (1 << SLOT_SHIFT);
@@ -579,102 +630,198 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
 #pragma unroll
     for (int k = 0; k < NM; k++) { kept_lo[k] = 0; kept_hi[k] = 0; }
     unsigned long long live_groups = 0ull;
-    auto group_masks = [&](const int j, const int cend, const float4 rec, const float4 pl, unsigned long long* out) {
+    // Can bundle sb (PRE 4) reach the sphere (centre, rho)?  The ray's LINE against the sphere widened by the
+    // origins' distance from the bundle's axis line, and the ray's HALF-line (the reference accepts no hit
+    // behind the origin, raytracer.cpp:325) against the sphere widened by the whole ball of origins.
+    auto bundle_reach = [&](const int sb, const float cx, const float cy, const float cz, const float rho) -> bool {
+        const float dx = cx - guard.qm[sb][0], dy = cy - guard.qm[sb][1], dz = cz - guard.qm[sb][2];
+        const float dist2 = dx * dx + dy * dy + dz * dz;
+        const float dist = sqrtf(dist2);
+        const float fwd = dx * guard.qa[sb][0] + dy * guard.qa[sb][1] + dz * guard.qa[sb][2];
+        const float cb = guard.qa[sb][3], sbn = guard.qa[sb][4];
+        const float R1 = (rho + guard.qm[sb][3]) * (1.0f + 1e-5f);
+        const float cs1 = sqrtf(fmaxf(dist2 - R1 * R1, 0.0f));
+        const bool line_reach = !(R1 < 0.999f * dist) | !(fabsf(fwd) < cs1 * cb - R1 * sbn - 1e-5f * dist);
+        const float R2 = (rho + guard.qm[sb][4]) * (1.0f + 1e-5f);
+        const float cs2 = sqrtf(fmaxf(dist2 - R2 * R2, 0.0f));
+        const bool half_reach = !(R2 < 0.999f * dist) | !(fwd < cs2 * cb - R2 * sbn - 1e-5f * dist);
+        return line_reach & half_reach;
+    };
+    // Can the task's cone of directions from the shared point (PRE 1, 2) reach the cone `rec` (unit axis, cosine)
+    // around a sphere?  Cones meet when the angle between their axes is at most the sum of their half-angles;
+    // and the sphere's axis may leave the fan's plane by at most the two angles together.
+    auto cone_reach = [&](const float4 rec) -> bool {
+        float along = rec.x * guard.bx + rec.y * guard.by + rec.z * guard.bz;
+        if (PRE == 2) along = fabsf(along);
+        const float ct = rec.w, st = sqrtf(fmaxf(1.0f - ct * ct, 0.0f));
+        const bool in_reach = (ct < -1.0f) | !(along < ct * guard.bcos - st * guard.bsin - 1e-5f);
+        const float aside = fabsf(rec.x * guard.fx + rec.y * guard.fy + rec.z * guard.fz);
+        const bool in_fan = (ct < -1.0f) | !(ct * guard.fcos - st * guard.fsin > 0.0f) |
+                            !(aside > st * guard.fcos + ct * guard.fsin + 1e-5f);
+        return in_reach & in_fan;
+    };
+    // PRE 3: the task's disc of origins in the light's plane against the disc `rec` = (-2 cu, -2 cv, rho^2 - c.c)
+    auto disc_reach = [&](const float4 rec) -> bool {
+        const float cu = -0.5f * rec.x, cv = -0.5f * rec.y;
+        const float rho = sqrtf(fmaxf(rec.z + cu * cu + cv * cv, 0.0f));      // (radius^2 = k + c.c; inf stays inf)
+        const float du = cu - guard.bx, dv = cv - guard.by, sum = rho + guard.bcos;
+        return !(du * du + dv * dv > sum * sum * (1.0f + 1e-5f));
+    };
+    // `reach_possible`: the group's cluster passed the test one level up (wave-uniform); otherwise only the
+    // in-plane-origin question is asked (PRE 4; the other kinds skip such groups altogether).
+    auto group_masks = [&](const int j, const int cend, const float4 rec, const float4 pl, const bool reach_possible,
+                           unsigned long long* out) {
         if (PRE == 4) {
-            // A line through P with direction V stays within |P - m| of the parallel line through m, so
-            // a bundle (origins within ro of m, directions within a cone) reaches the sphere (C, rho) only
-            // if a line through m inside that cone reaches (C, rho + ro).  In-plane-origin case: the
-            // triangle's plane passes through the ball of origins.
             // rec = centre, rho^2 - |C|^2; pl = (n, d0)
             const float rho = sqrtf(fmaxf(rec.w + rec.x * rec.x + rec.y * rec.y + rec.z * rec.z, 0.0f));
 #pragma unroll
             for (int q = 0; q < RPL / 2; q++) {
-                bool live = j < cend;
-                if (guard.qon[q] && j < cend) {
-                    const float dx = rec.x - guard.qm[q][0], dy = rec.y - guard.qm[q][1], dz = rec.z - guard.qm[q][2];
-                    const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
-                    const float sn = (rho + guard.qm[q][3]) * (1.0f + 1e-5f) / dist;
-                    const float along = fabsf(dx * guard.qa[q][0] + dy * guard.qa[q][1] + dz * guard.qa[q][2]) / dist;
-                    const float cs = sqrtf(fmaxf(1.0f - sn * sn, 0.0f));
-                    const bool in_reach = !(sn < 0.999f) | !(along < cs * guard.qa[q][3] - sn * guard.qa[q][4] - 1e-5f);
-                    const bool is_named = !(fabsf(pl.x * guard.qm[q][0] + pl.y * guard.qm[q][1] + pl.z * guard.qm[q][2] - pl.w) >
-                                            guard.qm[q][3] + 2.0f * guard.slack);
-                    live = in_reach | is_named;
+                bool live = false;
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const int sb = 2 * q + c;
+                    if (guard.qon[sb] < 0) continue;                     // (wave-uniform: the bundle holds no ray)
+                    if (guard.qon[sb] == 0) { live = true; continue; }
+                    // in-plane origin: the plane passes through the ball of origins and holds a grazing direction of the cone
+                    const float off = fabsf(pl.x * guard.qm[sb][0] + pl.y * guard.qm[sb][1] + pl.z * guard.qm[sb][2] - pl.w);
+                    const float g = fabsf(pl.x * guard.qa[sb][0] + pl.y * guard.qa[sb][1] + pl.z * guard.qa[sb][2]);
+                    // smallest |n . v| over the cone (<= 0: some v lies in the plane)
+                    const float steep = g * guard.qa[sb][3] - sqrtf(fmaxf(1.0f - g * g, 0.0f)) * guard.qa[sb][4];
+                    const bool is_named = !(off > guard.qm[sb][4] + 2.0f * guard.slack) & !(steep > guard.qgraze[sb]);
+                    live |= is_named;
+                    if (reach_possible) live |= bundle_reach(sb, rec.x, rec.y, rec.z, rho);
                 }
+                live &= j < cend;
                 out[q] = __ballot(live);
             }
         } else {
-            bool is_named = false, in_reach = j < cend;
-            if ((PRE == 2 || PRE == 3) && j < cend) {
-                // pl = (n, d0)
-                const float across = pl.x * guard.lx + pl.y * guard.ly + pl.z * guard.lz;
-                const float off = guard.point ? fabsf(pl.w - across) : fabsf(across);
-                const float centre = fabsf(pl.x * guard.cx + pl.y * guard.cy + pl.z * guard.cz - pl.w);
-                const float reach = fabsf(pl.x) * guard.hx + fabsf(pl.y) * guard.hy + fabsf(pl.z) * guard.hz + guard.slack;
-                is_named = !(off > guard.limit) && !(centre > reach);
+            bool in_reach = j < cend;
+            if (guard.cull && j < cend) in_reach = (PRE == 3) ? disc_reach(rec) : cone_reach(rec);
+            out[1] = 0ull;                               // (the plane guard's answers are added afterwards, see below)
+            out[0] = __ballot(in_reach);
+        }
+    };
+    // One level up: can a ray of the task reach anything in cluster `cl` (64 consecutive slots)?  Its record is
+    // the bound of the same kind around a sphere that holds the bounding spheres of its triangles.  The
+    // in-plane-origin case ignores where a triangle is and is asked separately:
+    //   camera rays: the cluster's record says "every direction" when the eye lies in a member's plane;
+    //   shadow rays: only triangles on the light's graze list can take that branch; the entries of the list
+    //     that fall into the chunk are asked the plane guard's question one by one (below);
+    //   reflection rays: per triangle, for every group (group_masks).
+    auto cluster_reach = [&](const int cl) -> bool {
+        const float4 rec = *(const float4*)(guard.cl_bounds + 4 * (size_t)cl);
+        if (PRE == 4) {
+            bool live = false;
+#pragma unroll
+            for (int sb = 0; sb < RPL; sb++) {
+                if (guard.qon[sb] < 0) continue;
+                if (guard.qon[sb] == 0) { live = true; continue; }
+                live |= bundle_reach(sb, rec.x, rec.y, rec.z, rec.w);
             }
-            if (guard.cull && j < cend) {
-                if (PRE == 3) {
-                    const float cu = -0.5f * rec.x, cv = -0.5f * rec.y;
-                    const float rho = sqrtf(fmaxf(rec.z + cu * cu + cv * cv, 0.0f));      // (radius^2 = k + c.c; inf stays inf)
-                    const float du = cu - guard.bx, dv = cv - guard.by, sum = rho + guard.bcos;
-                    in_reach = !(du * du + dv * dv > sum * sum * (1.0f + 1e-5f));
-                } else {
-                    float along = rec.x * guard.bx + rec.y * guard.by + rec.z * guard.bz;
-                    if (PRE == 2) along = fabsf(along);
-                    const float ct = rec.w, st = sqrtf(fmaxf(1.0f - ct * ct, 0.0f));
-                    in_reach = (ct < -1.0f) | !(along < ct * guard.bcos - st * guard.bsin - 1e-5f);
-                    // ... and the sphere's axis may leave the fan's plane by at most the two angles together
-                    const float aside = fabsf(rec.x * guard.fx + rec.y * guard.fy + rec.z * guard.fz);
-                    const bool in_fan = (ct < -1.0f) | !(ct * guard.fcos - st * guard.fsin > 0.0f) |
-                                        !(aside > st * guard.fcos + ct * guard.fsin + 1e-5f);
-                    in_reach &= in_fan;
-                }
-            }
-            out[1] = __ballot(is_named);
-            out[0] = __ballot(in_reach | is_named);
+            return live;
+        } else {
+            if (!guard.cull) return true;
+            return (PRE == 3) ? disc_reach(rec) : cone_reach(rec);
         }
     };
     for (cbeg = abeg; cbeg < aend; cbeg += CHUNK) {
         const int cend = min(cbeg + CHUNK, aend);
         n_cand = 0;
+#ifdef RT_X_CYCLES
+        const unsigned long long t_judge0 = __builtin_readcyclecounter();
+#endif
         if (PRE) {
             live_groups = 0ull;
             const int n_grp = (cend - cbeg + 63) >> 6;
-            for (int g0 = 0; g0 < n_grp; g0 += RT_GROUPS_AHEAD) {
+            // clusters first, one per lane (a chunk holds at most 64 and starts at a multiple of 64) ...
+            const unsigned long long cl_reach = __ballot(lane < n_grp && cluster_reach((cbeg >> 6) + lane));
+            if (WORK) wk.v[RT_WK_CLUSTERS] += (unsigned int)n_grp;
+            // ... then the triangles, one per lane, RT_GROUPS_AHEAD groups per round: of the clusters that
+            // passed, and (reflection rays) of the others for the in-plane-origin question alone
+            unsigned long long todo = (PRE == 4) ? ((n_grp >= 64) ? ~0ull : ((1ull << n_grp) - 1ull)) : cl_reach;
+            while (todo != 0ull) {
+                int gi[RT_GROUPS_AHEAD];
                 float4 rec[RT_GROUPS_AHEAD], pl[RT_GROUPS_AHEAD];
 #pragma unroll
                 for (int u = 0; u < RT_GROUPS_AHEAD; u++) {
-                    const int j = cbeg + (g0 + u) * 64 + lane;
+                    gi[u] = -1;
+                    if (todo != 0ull) { gi[u] = (int)__builtin_ctzll(todo); todo &= todo - 1ull; }
+                    const int j = cbeg + gi[u] * 64 + lane;
                     rec[u] = make_float4(0.f, 0.f, 0.f, 0.f); pl[u] = rec[u];
-                    if (j < cend) {
-                        rec[u] = *(const float4*)(guard.bounds + 4 * (size_t)j);
+                    if (gi[u] >= 0 && j < cend) {
+                        if (PRE != 4 || ((cl_reach >> gi[u]) & 1ull)) rec[u] = *(const float4*)(guard.bounds + 4 * (size_t)j);
                         if (PRE == 4) pl[u] = *(const float4*)(guard.planes + 4 * (size_t)j);
-                        if (PRE == 2 || PRE == 3) pl[u] = *(const float4*)(guard.records + 16 * (size_t)j);
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < RT_GROUPS_AHEAD; u++) {
-                    if (g0 + u < n_grp) {
+                    if (gi[u] >= 0) {
                         unsigned long long out[NM];
-                        group_masks(cbeg + (g0 + u) * 64 + lane, cend, rec[u], pl[u], out);
+                        const bool reach_possible = (cl_reach >> gi[u]) & 1ull;
+                        group_masks(cbeg + gi[u] * 64 + lane, cend, rec[u], pl[u], reach_possible, out);
+                        if (WORK) {
+                            wk.v[RT_WK_GROUPS]++;
+#ifndef RT_X_CYCLES
+                            if (reach_possible) wk.v[RT_WK_GROUP_TESTS] += (unsigned int)min(64, cend - (cbeg + gi[u] * 64)) * (PRE == 4 ? RPL : 1);
+#endif
+                        }
                         unsigned long long any = out[0];
                         if (PRE == 4) {
 #pragma unroll
                             for (int k = 1; k < NM; k++) any |= out[k];
                         }
                         if (any != 0ull) {
-                            live_groups |= 1ull << (g0 + u);
+                            if (WORK) wk.v[RT_WK_GROUPS_LIVE]++;
+                            live_groups |= 1ull << gi[u];
 #pragma unroll
                             for (int k = 0; k < NM; k++) {
-                                kept_lo[k] = (lane == g0 + u) ? (int)(unsigned int)out[k] : kept_lo[k];
-                                kept_hi[k] = (lane == g0 + u) ? (int)(unsigned int)(out[k] >> 32) : kept_hi[k];
+                                kept_lo[k] = (lane == gi[u]) ? (int)(unsigned int)out[k] : kept_lo[k];
+                                kept_hi[k] = (lane == gi[u]) ? (int)(unsigned int)(out[k] >> 32) : kept_hi[k];
                             }
                         }
                     }
                 }
             }
+            if (PRE == 2 || PRE == 3) {
+                // The plane guard: the light's graze-list entries inside this chunk, one per lane.  An entry is
+                // named when the light is close enough to its plane for THIS task's rays (the list was cut for
+                // the whole scene's) and the plane passes through the box around the task's origins.
+                const int e0 = guard.graze_start[cbeg >> 6], e1 = guard.graze_start[(cend + 63) >> 6];
+                for (int eb = e0; eb < e1; eb += RT_WAVE) {
+                    const int e = eb + lane;
+                    int j = -1;
+                    bool is_named = false;
+                    if (e < e1) {
+                        j = guard.graze_slots[e];
+                        const float4 p4 = *(const float4*)(guard.planes + 4 * (size_t)j);
+                        const float across = p4.x * guard.lx + p4.y * guard.ly + p4.z * guard.lz;
+                        const float off = guard.point ? fabsf(p4.w - across) : fabsf(across);
+                        const float centre = fabsf(p4.x * guard.cx + p4.y * guard.cy + p4.z * guard.cz - p4.w);
+                        const float reach = fabsf(p4.x) * guard.hx + fabsf(p4.y) * guard.hy + fabsf(p4.z) * guard.hz + guard.slack;
+                        is_named = !(off > guard.limit) && !(centre > reach) && j >= cbeg && j < cend;
+                    }
+                    unsigned long long hits = __ballot(is_named);
+                    while (hits != 0ull) {                        // (rare)
+                        const int src = (int)__builtin_ctzll(hits);
+                        hits &= hits - 1ull;
+                        const int rel = __builtin_amdgcn_readlane(j, src) - cbeg;
+                        const int g = rel >> 6, bit = rel & 63;
+                        const int lo_bit = bit < 32 ? (int)(1u << bit) : 0, hi_bit = bit < 32 ? 0 : (int)(1u << (bit - 32));
+#pragma unroll
+                        for (int k = 0; k < 2; k++) {
+                            const int had_lo = ((live_groups >> g) & 1ull) ? kept_lo[k] : 0, had_hi = ((live_groups >> g) & 1ull) ? kept_hi[k] : 0;
+                            kept_lo[k] = (lane == g) ? (had_lo | lo_bit) : kept_lo[k];
+                            kept_hi[k] = (lane == g) ? (had_hi | hi_bit) : kept_hi[k];
+                        }
+                        live_groups |= 1ull << g;
+                    }
+                }
+            }
         }
+#ifdef RT_X_CYCLES
+        const unsigned long long t_judge1 = __builtin_readcyclecounter();
+        if (WORK) wk.v[RT_WK_GROUP_TESTS] += (unsigned int)((t_judge1 - t_judge0) >> 4);
+#endif
         for (int j0 = cbeg; j0 < cend; j0 += RT_BATCH) {
             int jn = min(j0 + RT_BATCH, cend);
             int j_next = j0 + RT_BATCH;               // where the scan goes on after this batch
@@ -755,6 +902,12 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                     nxt_index = jl;
                 }
                 if (PRE == 2 || PRE == 3) named = (unsigned int)(guard_mask >> (j0 - guard_base)) & ((1u << RT_BATCH) - 1u);
+                if (WORK) {
+                    wk.v[RT_WK_BATCHES]++;
+#ifndef RT_X_CYCLES
+                    if (PRE != 4) wk.v[RT_WK_RAY_BOUND_TESTS] += RT_WAVE * RPL * RT_BATCH;
+#endif
+                }
 #pragma unroll
                 for (int jb = 0; jb < RT_BATCH; jb++) {
                     const float ax = cones_cur[4 * jb], ay = cones_cur[4 * jb + 1], az = cones_cur[4 * jb + 2];
@@ -806,6 +959,9 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
 #pragma unroll
                     for (int q = 0; q < RPL / 2; q++) {
                         if (((pair_mask[q] >> (j0 - guard_base)) & ((1ull << RT_BATCH) - 1ull)) == 0ull) continue;
+#ifndef RT_X_CYCLES
+                        if (WORK) wk.v[RT_WK_RAY_BOUND_TESTS] += RT_WAVE * 2 * RT_BATCH;
+#endif
                         v2f t[RT_BATCH], d[RT_BATCH], a[RT_BATCH];
 #pragma unroll
                         for (int jb = 0; jb < RT_BATCH; jb++) {
@@ -850,10 +1006,18 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                     unsigned int want = named;
 #pragma unroll
                     for (int jb = 0; jb < RT_BATCH; jb++) want |= wants[jb] ? (1u << jb) : 0u;
+                    if (WORK) wk.v[RT_WK_BATCHES_TESTED]++;
 #pragma unroll 1
                     for (int jb = 0; jb < RT_BATCH; jb++) {
                         const int j = j0 + jb;
                         if (j >= jn) break;
+                        if (WORK) {
+                            const unsigned long long asking = __ballot((want >> jb) & 1u);
+                            if (asking) {
+                                wk.v[RT_WK_TRI_TESTS] += RT_WAVE * RPL;
+                                wk.v[RT_WK_TRI_WANTED] += (unsigned int)__popcll(asking) * RPL;
+                            }
+                        }
                         if ((want >> jb) & 1u) test_triangle(j, filt[j], SHARED ? shared[j] : 0.0f);
                     }
                 }
@@ -863,6 +1027,10 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                 // array carries padding records, so j+1 is always readable).
                 v16f cur = filt[j0];
                 float sh_cur = SHARED ? shared[j0] : 0.0f;
+                if (WORK) {
+                    wk.v[RT_WK_TRI_TESTS] += (unsigned int)(jn - j0) * RT_WAVE * RPL;
+                    wk.v[RT_WK_TRI_WANTED] += (unsigned int)(jn - j0) * RT_WAVE * RPL;
+                }
                 for (int j = j0; j < jn; j++) {
                     const v16f nxt = filt[j + 1];
                     const float sh_nxt = SHARED ? shared[j + 1] : 0.0f;
@@ -875,11 +1043,15 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
             // and at the end of the chunk (entries are relative to the chunk base).
             const bool last = j_next >= cend;
             if (__any(n_cand > RT_CAND_CAP - RT_BATCH * RPL) || (last && __any(n_cand > 0))) {
-                flush_candidates<RPL>(A, my_cand, n_cand, cbeg, ray0, n_rays, lane);
+                const int listed = flush_candidates<RPL>(A, my_cand, n_cand, cbeg, ray0, n_rays, lane);
+                if (WORK) wk.v[RT_WK_LISTED] += (unsigned int)listed;
                 n_cand = 0;
             }
             j0 = j_next - RT_BATCH;
         }
+#ifdef RT_X_CYCLES
+        if (WORK) wk.v[RT_WK_RAY_BOUND_TESTS] += (unsigned int)((__builtin_readcyclecounter() - t_judge1) >> 4);
+#endif
     }
 }
 
@@ -887,7 +1059,7 @@ __device__ __forceinline__ float uniform_f(float x) {      // a value every lane
     return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
 }
 
-template <int MODE, int RPL, bool ROBUST, int CONE>
+template <int MODE, int RPL, bool ROBUST, int CONE, bool WORK = false>
 __global__ void __launch_bounds__(RT_BLOCK, RT_FILTER_MIN_WAVES)
 k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, TraceArgs A) {
     // The filter records are never written while a kernel runs: reading them through the
@@ -954,6 +1126,12 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
         }
         first_task = false;
         if (task >= n_tasks) break;
+        WorkCount wk = {};
+        if (WORK) wk.v[RT_WK_TASKS] = 1;
+#ifdef RT_X_CYCLES
+        const unsigned long long t_task0 = __builtin_readcyclecounter();
+        unsigned long long t_setup = 0;
+#endif
         // integer division goes through the vector ALU; its result is still wave-uniform
         const int part = __builtin_amdgcn_readfirstlane((int)(task / n_ray_blocks));
         const unsigned int rb = task - (unsigned int)part * n_ray_blocks;
@@ -998,9 +1176,11 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
         for (int g = 0; g < n_groups; g++) {
             // group records are the same for every lane: keep the bounds in scalar registers
             const Group& G = sc->groups[g];
-            int fax[4];
+            int fax[4], fcnt[3];
 #pragma unroll
             for (int k = 0; k < 4; k++) fax[k] = __builtin_amdgcn_readfirstlane(G.fax[k]);
+#pragma unroll
+            for (int k = 0; k < 3; k++) fcnt[k] = __builtin_amdgcn_readfirstlane(G.fcnt[k]);
             // Shadow rays are tested against every group's untransformed geometry
             // (raytracer.cpp:553): for them the groups only delimit the axis ranges.
             const int ident = (MODE == 0) ? __builtin_amdgcn_readfirstlane(G.identity) : 1;
@@ -1090,7 +1270,14 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                 }
             }
             PlaneGuard guard = {};
-            if (CONE == 4) guard.planes = A.plane_any;
+            if (CONE == 4) { guard.planes = A.plane_any; guard.cl_bounds = A.cl_sphere; guard.cl_normals = A.cl_normal; }
+            if (CONE == 1) guard.cl_bounds = A.cl_camera;
+            if (CONE == 2) {
+                guard.cl_bounds = A.cl_lights + (size_t)light * (size_t)(A.n_clusters + 1) * 4;
+                guard.graze_slots = A.graze_slots;
+                guard.graze_start = A.graze_start + (size_t)light * (size_t)(A.n_clusters + 1);
+                guard.planes = A.plane_any;
+            }
             if (CONE == 2) {
                 float m = reach_max;
                 for (int off = 32; off > 0; off >>= 1) {
@@ -1130,29 +1317,100 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                 for (int k = 0; k < RPL / 2; k++) {
                     const v2f sc2 = {sqrtf(L.hz[k].x), sqrtf(L.hz[k].y)};                       // hz = 1 / |V|^2
                     const v2f ux = L.vx[k] * sc2, uy = L.vy[k] * sc2, uz = L.vz[k] * sc2;
-                    float sx = ux.x + ux.y, sy = uy.x + uy.y, sz = uz.x + uz.y;
-                    float ox = L.px[k].x + L.px[k].y, oy = L.py[k].x + L.py[k].y, oz = L.pz[k].x + L.pz[k].y;
-                    for (int off = 32; off > 0; off >>= 1) {
-                        sx += __shfl_xor(sx, off); sy += __shfl_xor(sy, off); sz += __shfl_xor(sz, off);
-                        ox += __shfl_xor(ox, off); oy += __shfl_xor(oy, off); oz += __shfl_xor(oz, off);
+                    // members: the rays whose candidates count (a slot past the queue's end or a ray outside the
+                    // filter's bounds lists nothing, so nothing has to be promised about it)
+                    const bool in0 = (L.on >> (2 * k)) & 1u, in1 = (L.on >> (2 * k + 1)) & 1u;
+                    // Rays reflected by one flat facet run together like a camera's; a pair of slots that
+                    // straddles two facets holds two such beams some 10-40 degrees apart, and one cone around
+                    // both reaches half the scene.  So: the ray farthest from the mean direction seeds one
+                    // bundle, the ray farthest from that one the other, every ray joins the nearer seed.
+                    float s0 = (in0 ? ux.x : 0.f) + (in1 ? ux.y : 0.f), s1 = (in0 ? uy.x : 0.f) + (in1 ? uy.y : 0.f),
+                          s2 = (in0 ? uz.x : 0.f) + (in1 ? uz.y : 0.f);
+                    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off); s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+                    const float inv0 = 1.0f / sqrtf(s0 * s0 + s1 * s1 + s2 * s2);
+                    const float a0x = s0 * inv0, a0y = s1 * inv0, a0z = s2 * inv0;
+                    const float d0x = in0 ? a0x * ux.x + a0y * uy.x + a0z * uz.x : 2.f, d0y = in1 ? a0x * ux.y + a0y * uy.y + a0z * uz.y : 2.f;
+                    float low0 = fminf(d0x, d0y);
+                    const float mine0 = low0;
+                    for (int off = 32; off > 0; off >>= 1) low0 = fminf(low0, __shfl_xor(low0, off));
+                    bool b0 = false, b1 = false;                       // which of the lane's two rays belong to the second bundle
+                    // (NaN anywhere: low0 is NaN or 2, no split; the bundle below then reports "no bound")
+                    if (low0 < 0.99985f) {                              // wave-uniform: more than about 1 degree apart
+                        int src = (int)__builtin_ctzll(__ballot(mine0 == low0) | (1ull << 63));
+                        const bool first = d0x <= d0y;
+                        const float e1x = __shfl(first ? ux.x : ux.y, src), e1y = __shfl(first ? uy.x : uy.y, src),
+                                    e1z = __shfl(first ? uz.x : uz.y, src);
+                        const float d1x = in0 ? e1x * ux.x + e1y * uy.x + e1z * uz.x : 2.f, d1y = in1 ? e1x * ux.y + e1y * uy.y + e1z * uz.y : 2.f;
+                        float low1 = fminf(d1x, d1y);
+                        const float mine1 = low1;
+                        for (int off = 32; off > 0; off >>= 1) low1 = fminf(low1, __shfl_xor(low1, off));
+                        src = (int)__builtin_ctzll(__ballot(mine1 == low1) | (1ull << 63));
+                        const bool first1 = d1x <= d1y;
+                        const float e2x = __shfl(first1 ? ux.x : ux.y, src), e2y = __shfl(first1 ? uy.x : uy.y, src),
+                                    e2z = __shfl(first1 ? uz.x : uz.y, src);
+                        b0 = e2x * ux.x + e2y * uy.x + e2z * uz.x > d1x;
+                        b1 = e2x * ux.y + e2y * uy.y + e2z * uz.y > d1y;
                     }
-                    const float inv = 1.0f / sqrtf(sx * sx + sy * sy + sz * sz);
-                    const float ax = sx * inv, ay = sy * inv, az = sz * inv;
-                    const float mx = ox * (1.0f / (2 * RT_WAVE)), my = oy * (1.0f / (2 * RT_WAVE)), mz = oz * (1.0f / (2 * RT_WAVE));
-                    float low = fminf(ax * ux.x + ay * uy.x + az * uz.x, ax * ux.y + ay * uy.y + az * uz.y);
-                    const float ex = L.px[k].x - mx, ey = L.py[k].x - my, ez = L.pz[k].x - mz;
-                    const float fx2 = L.px[k].y - mx, fy2 = L.py[k].y - my, fz2 = L.pz[k].y - mz;
-                    float far2 = fmaxf(ex * ex + ey * ey + ez * ez, fx2 * fx2 + fy2 * fy2 + fz2 * fz2);
-                    for (int off = 32; off > 0; off >>= 1) { low = fminf(low, __shfl_xor(low, off)); far2 = fmaxf(far2, __shfl_xor(far2, off)); }
-                    const float ro = sqrtf(far2) * (1.0f + 1e-5f) + 1e-6f * (fabsf(mx) + fabsf(my) + fabsf(mz));
-                    const float cb = low - 4e-6f;
-                    // (a NaN anywhere makes the axis NaN: fminf would drop it, the flags do not)
-                    const bool finite = (ax == ax) && (ay == ay) && (az == az) && (ro == ro) && (low == low);
-                    guard.qa[k][0] = uniform_f(ax); guard.qa[k][1] = uniform_f(ay); guard.qa[k][2] = uniform_f(az);
-                    guard.qa[k][3] = uniform_f(cb); guard.qa[k][4] = uniform_f(sqrtf(fmaxf(1.0f - cb * cb, 0.0f)) + 1e-6f);
-                    guard.qm[k][0] = uniform_f(mx); guard.qm[k][1] = uniform_f(my); guard.qm[k][2] = uniform_f(mz);
-                    guard.qm[k][3] = uniform_f(ro);
-                    guard.qon[k] = __builtin_amdgcn_readfirstlane((finite && cb > 0.0f) ? 1 : 0);
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        const int sb = 2 * k + c;
+                        const bool m0 = in0 && (b0 == (c == 1)), m1 = in1 && (b1 == (c == 1));
+                        float sx = (m0 ? ux.x : 0.f) + (m1 ? ux.y : 0.f), sy = (m0 ? uy.x : 0.f) + (m1 ? uy.y : 0.f),
+                              sz = (m0 ? uz.x : 0.f) + (m1 ? uz.y : 0.f);
+                        float ox = (m0 ? L.px[k].x : 0.f) + (m1 ? L.px[k].y : 0.f), oy = (m0 ? L.py[k].x : 0.f) + (m1 ? L.py[k].y : 0.f),
+                              oz = (m0 ? L.pz[k].x : 0.f) + (m1 ? L.pz[k].y : 0.f);
+                        float cnt = (m0 ? 1.f : 0.f) + (m1 ? 1.f : 0.f);
+                        float slow = fmaxf(m0 ? L.hz[k].x : 0.f, m1 ? L.hz[k].y : 0.f);        // largest 1 / |V|^2
+                        for (int off = 32; off > 0; off >>= 1) {
+                            sx += __shfl_xor(sx, off); sy += __shfl_xor(sy, off); sz += __shfl_xor(sz, off);
+                            ox += __shfl_xor(ox, off); oy += __shfl_xor(oy, off); oz += __shfl_xor(oz, off);
+                            cnt += __shfl_xor(cnt, off); slow = fmaxf(slow, __shfl_xor(slow, off));
+                        }
+                        const float inv = 1.0f / sqrtf(sx * sx + sy * sy + sz * sz);
+                        const float ax = sx * inv, ay = sy * inv, az = sz * inv;
+                        const float icnt = 1.0f / cnt;
+                        const float mx = ox * icnt, my = oy * icnt, mz = oz * icnt;
+                        // per ray: cosine to the axis; its origin's offset from the centre, along and across the axis
+                        const float ex = L.px[k].x - mx, ey = L.py[k].x - my, ez = L.pz[k].x - mz;
+                        const float fx2 = L.px[k].y - mx, fy2 = L.py[k].y - my, fz2 = L.pz[k].y - mz;
+                        const float el = ex * ax + ey * ay + ez * az, fl = fx2 * ax + fy2 * ay + fz2 * az;
+                        const float e2 = ex * ex + ey * ey + ez * ez, f2 = fx2 * fx2 + fy2 * fy2 + fz2 * fz2;
+                        float low = fminf(m0 ? ax * ux.x + ay * uy.x + az * uz.x : 1.f, m1 ? ax * ux.y + ay * uy.y + az * uz.y : 1.f);
+                        float far2 = fmaxf(m0 ? e2 : 0.f, m1 ? f2 : 0.f);
+                        float across2 = fmaxf(m0 ? e2 - el * el : 0.f, m1 ? f2 - fl * fl : 0.f);
+                        float along1 = fmaxf(m0 ? fabsf(el) : 0.f, m1 ? fabsf(fl) : 0.f);
+                        for (int off = 32; off > 0; off >>= 1) {
+                            low = fminf(low, __shfl_xor(low, off)); far2 = fmaxf(far2, __shfl_xor(far2, off));
+                            across2 = fmaxf(across2, __shfl_xor(across2, off)); along1 = fmaxf(along1, __shfl_xor(along1, off));
+                        }
+                        const float cb = low - 4e-6f;
+                        const float sn = sqrtf(fmaxf(1.0f - cb * cb, 0.0f)) + 1e-6f;
+                        const float pad = 1e-6f * (fabsf(mx) + fabsf(my) + fabsf(mz));
+                        const float rfull = sqrtf(far2) * (1.0f + 1e-5f) + pad;
+                        // A line through P with direction v stays within |P - m|'s part across v of the parallel line
+                        // through m: at most the part across the axis plus the part along it times the sine of the
+                        // angle between v and the axis.  (The square of the part across the axis is a difference of
+                        // squares: its rounding, a few ulps of |P - m|^2, goes on top.)
+                        const float racross = sqrtf(fmaxf(across2, 0.0f) + 8e-7f * far2) * (1.0f + 1e-5f) + along1 * sn * (1.0f + 1e-5f) + pad;
+                        // (a NaN anywhere makes the axis NaN: fminf would drop it, the flags do not)
+                        const bool finite = (ax == ax) && (ay == ay) && (az == az) && (rfull == rfull) && (racross == racross) && (low == low);
+                        guard.qa[sb][0] = uniform_f(ax); guard.qa[sb][1] = uniform_f(ay); guard.qa[sb][2] = uniform_f(az);
+                        guard.qa[sb][3] = uniform_f(cb); guard.qa[sb][4] = uniform_f(sn);
+                        guard.qm[sb][0] = uniform_f(mx); guard.qm[sb][1] = uniform_f(my); guard.qm[sb][2] = uniform_f(mz);
+                        guard.qm[sb][3] = uniform_f(fminf(racross, rfull)); guard.qm[sb][4] = uniform_f(rfull);
+                        // |n . V| <= b_hi with V = |V| v: |n . v| <= b_hi / |V| <= b_hi * sqrt(largest 1 / |V|^2)
+                        guard.qgraze[sb] = uniform_f(fp.b_hi * sqrtf(slow) * (1.0f + 1e-4f) + 4e-6f);
+                        guard.qon[sb] = __builtin_amdgcn_readfirstlane(!(cnt > 0.5f) ? -1 : ((finite && cb > 0.0f) ? 1 : 0));
+#ifdef RT_X_HIST
+                        if (WORK && lane == 0 && A.work && part == 0 && cnt > 0.5f) {
+                            const float cbu = uniform_f(cb), rou = uniform_f(fminf(racross, rfull));
+                            int bin = cbu > 0.99985f ? 0 : cbu > 0.99939f ? 1 : cbu > 0.9962f ? 2 : cbu > 0.9848f ? 3 : cbu > 0.9397f ? 4 : cbu > 0.7071f ? 5 : 6;
+                            atomicAdd(&A.work[bin], 1ull);
+                            int rbin = rou < 0.01f ? 7 : rou < 0.05f ? 8 : 9;
+                            atomicAdd(&A.work[rbin], 1ull);
+                        }
+#endif
+                    }
                 }
             }
             if (CONE == 1 || CONE == 2) {
@@ -1227,16 +1485,20 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
 #pragma unroll
                 for (int k = 0; k < RPL / 2; k++) { L.px[k] = {ex, ex}; L.py[k] = {ey, ey}; L.pz[k] = {ez, ez}; }
             }
+#ifdef RT_X_CYCLES
+            t_setup = __builtin_readcyclecounter() - t_task0;
+#endif
             // each part takes its share of every axis range
 #pragma unroll
             for (int axis = 0; axis < 3; axis++) {
-                const int alen = fax[axis + 1] - fax[axis];
-                const int per_part = __builtin_amdgcn_readfirstlane((alen + split - 1) / split);
+                const int alen = fcnt[axis];
+                // (parts begin at multiples of 64, like the axis ranges: clusters are never cut)
+                const int per_part = __builtin_amdgcn_readfirstlane((((alen + split - 1) / split) + 63) & ~63);
                 const int abeg = fax[axis] + part * per_part;
-                const int aend = min(fax[axis + 1], abeg + per_part);
+                const int aend = min(fax[axis] + alen, abeg + per_part);
                 if (abeg >= aend) continue;
                 constexpr int KIND = (MODE == 0) ? 1 : 2;
-#define RT_RANGE(AX, SH, PR) filter_range<MODE, RPL, AX, ROBUST, SH, PR>(filt, shared, cone, guard, A, L, fp, abeg, aend, my_cand, ray0, ray_end, lane)
+#define RT_RANGE(AX, SH, PR) filter_range<MODE, RPL, AX, ROBUST, SH, PR, WORK>(filt, shared, cone, guard, A, L, fp, abeg, aend, my_cand, ray0, ray_end, lane, wk)
                 if (CONE == 1) {
                     if (axis == 0) RT_RANGE(0, 1, 1);
                     if (axis == 1) RT_RANGE(1, 1, 1);
@@ -1259,7 +1521,7 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                         D.hx[k] = L.vx[k]; D.hy[k] = L.vy[k]; D.hz[k] = L.vz[k];
                         D.vx[k] = {sx, sx}; D.vy[k] = {sy, sy}; D.vz[k] = {sz, sz};
                     }
-#define RT_RANGE_D(AX) filter_range<MODE, RPL, AX, ROBUST, 2, 3>(filt, shared, cone, guard, A, D, fp, abeg, aend, my_cand, ray0, ray_end, lane)
+#define RT_RANGE_D(AX) filter_range<MODE, RPL, AX, ROBUST, 2, 3, WORK>(filt, shared, cone, guard, A, D, fp, abeg, aend, my_cand, ray0, ray_end, lane, wk)
                     if (axis == 0) RT_RANGE_D(0);
                     if (axis == 1) RT_RANGE_D(1);
                     if (axis == 2) RT_RANGE_D(2);
@@ -1275,6 +1537,18 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                 }
 #undef RT_RANGE
             }
+        }
+#ifdef RT_X_CYCLES
+        if (WORK) {
+            wk.v[RT_WK_TRI_WANTED] = (unsigned int)(t_setup >> 4);
+            wk.v[RT_WK_TRI_TESTS] = (unsigned int)((__builtin_readcyclecounter() - t_task0) >> 4);
+        }
+#endif
+        if (WORK && lane == 0 && A.work) {
+            const int kind = (CONE == 1) ? 1 : (CONE == 4) ? 4 : (CONE == 2) ? cone_kind : (MODE == 0 ? 0 : 5);
+#pragma unroll
+            for (int f = 0; f < RT_WORK_FIELDS; f++)
+                if (wk.v[f]) atomicAdd(&A.work[kind * RT_WORK_FIELDS + f], (unsigned long long)wk.v[f]);
         }
     }
 }
@@ -1297,6 +1571,8 @@ k_exact_pairs(const DevScene* __restrict__ sc, const TriExact* __restrict__ exac
         // producer bug from turning into an out-of-range access.
         if (ray >= n_rays || slot >= n_regular) continue;
         const TriExact& T = exact[slot];
+        // (no scan lists a hole; asked only at the end, so that this load does not stand in front of the others)
+        const bool is_hole = T.hole != 0;
         int ident = 1;
         const double* X = sc->xforms;
         if (MODE == 0) {
@@ -1310,6 +1586,7 @@ k_exact_pairs(const DevScene* __restrict__ sc, const TriExact* __restrict__ exac
         to_object_space(X, ident, &pos, &vec);
         bool q7 = false;
         const float t = tri_intersect_exact(T, pos, vec, eps, &q7);
+        if (is_hole) continue;
         if (q7) atomicAdd(&A.counters->in_plane_origin_hits, 1ull);
         publish_result<MODE>(A, ray, n_hits, t, T.obj, pos, vec, X, ident, source);
     }
@@ -1405,6 +1682,7 @@ k_brute(const DevScene* __restrict__ sc, const TriExact* __restrict__ exact, Tra
                     const unsigned int bray = (unsigned int)__shfl((int)ray, src);
                     const int bsource = __shfl(source, src);
                     for (int j = pbeg + lane; j < pend; j += RT_WAVE) {
+                        if (exact[j].hole) continue;
                         const float t = tri_intersect_exact(exact[j], bpos, bvec, eps);
                         publish_result<MODE>(A, bray, n_hits, t, exact[j].obj, bpos, bvec, X, ident, bsource);
                         n_exact++;
@@ -1691,7 +1969,7 @@ k_fold(FoldArgs A) {
 __global__ void k_count(const DevScene* __restrict__ sc, const uint32_t* __restrict__ counts, int levels,
                         DevCounters* __restrict__ c) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    unsigned long long prims = (unsigned long long)sc->n_regular + sc->n_irregular + sc->n_spheres;
+    unsigned long long prims = (unsigned long long)sc->n_prims_nominal;
     unsigned long long rays = 0, hits = 0;
     for (int k = 0; k < levels; k++) { rays += counts[k]; hits += counts[k + 1]; }
     c->rays_primary += counts[0];

@@ -41,7 +41,7 @@ def test_struct_sizes_match_c():
     assert C.sizeof(abi.RtTransform) == 48 * 8
     assert C.sizeof(abi.RtLight) == 6 * 8 + 8
     assert C.sizeof(abi.RtSceneDesc) == 24 + 18 * 8 + 16 + 9 * 8
-    assert C.sizeof(abi.RtStats) == 11 * 8 + 3 * 8 + 3 * 4 + 5 * 4 + 8 + 2 * 4
+    assert C.sizeof(abi.RtStats) == 11 * 8 + 3 * 8 + 3 * 4 + 5 * 4 + 8 + 2 * 4 + 6 * 11 * 8 + 6 * 8 + 6 * 4
 
 
 def test_upload_without_gpu_fails_loudly():

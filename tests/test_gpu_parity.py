@@ -164,6 +164,45 @@ def test_two_streams_give_the_frame_of_one(name, w, h, depth, bvh):
         assert frames[0][1][k] == frames[1][1][k], k
 
 
+@pytest.mark.parametrize("name,w,h,depth", [("teapot", 640, 360, 5), ("mixed_xf", 320, 240, 4), ("input-11", 200, 160, 6)])
+def test_work_counters_change_nothing_and_add_up(name, w, h, depth):
+    """RT_OPT_WORK_COUNTERS runs the scans in instances that count what they execute.  Same frame, same ray
+    counts; the counts are consistent with each other and with the nominal pair counts."""
+    from raytracer_amd.render import Renderer
+    sc = Scene.load(scene_file(name), w, h, depth)
+    base, sb = gpu_render(sc)
+    for bounding in (1, 0):
+        r = Renderer(sc)
+        r.set_option(abi.RT_OPT_BOUNDING_TESTS, bounding)
+        r.set_option(abi.RT_OPT_WORK_COUNTERS, 1)
+        r.render_frame()
+        img, st = r.download(), r.stats()
+        r.close()
+        assert np.array_equal(img, base)
+        for k in ("rays_primary", "rays_reflect", "rays_shadow", "hits"):
+            assert st[k] == sb[k], k
+        work = st["scan_work"]
+        n_tri = st["n_triangles"] - st["n_irregular"]
+        if n_tri == 0:
+            continue
+        for kind, wk in work.items():
+            assert wk["tri_tests_wanted"] <= wk["tri_tests"], kind
+            assert wk["groups_live"] <= wk["groups"], kind
+            assert wk["batches_tested"] <= wk["batches"] or kind.startswith("plain"), kind
+        if bounding == 0:
+            # every pair takes the triangle test: whole waves of 64 lanes x 8 ray slots per triangle, so the
+            # executed count is the nominal one rounded up to whole tasks
+            rays0 = st["rays_primary"] + st["rays_reflect"]
+            assert work["plain_nearest"]["tri_tests"] >= rays0 * n_tri
+            assert work["plain_shadow"]["tri_tests"] >= st["rays_shadow"] * n_tri
+            assert work["camera"]["tasks"] == work["reflection"]["tasks"] == 0
+        else:
+            assert work["plain_nearest"]["tasks"] == 0 and work["camera"]["tasks"] > 0
+            # a bounded scan executes fewer triangle tests than there are pairs
+            if n_tri >= 256:
+                assert work["camera"]["tri_tests"] < st["rays_primary"] * n_tri
+
+
 def test_filter_form_follows_the_scene():
     """Large smooth triangles take the cheap static margins; a mesh of triangles that are tiny
     against its scene, or that has walls of coplanar triangles, takes per-test margins and then
