@@ -26,7 +26,8 @@ $(PKG)/libraytracer_amd.so: $(HIP_SRC) $(HIP_HDR)
 
 # The host driver (the reference's main): links both libraries, found at run time next to itself.
 $(PKG)/rt_render: $(PKG)/host/rt_cli.cpp $(PKG)/librt_host.so $(PKG)/libraytracer_amd.so include/rt_abi.h include/rt_host.h
-	$(CXX) -O2 -std=c++17 -Iinclude -o $@ $(PKG)/host/rt_cli.cpp -L$(PKG) -lrt_host -lraytracer_amd -Wl,-rpath,'$$ORIGIN' -Wl,-rpath-link,/opt/rocm/lib
+	$(CXX) -O2 -std=c++17 -pthread -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include -o $@ $(PKG)/host/rt_cli.cpp -L$(PKG) -lrt_host -lraytracer_amd \
+	  -L/opt/rocm/lib -lamdhip64 -lrccl -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 
 oracle:
 	$(MAKE) -C oracle all
@@ -48,7 +49,7 @@ asan:
 	$(HIPCC) --offload-arch=gfx950 -O1 -g -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -Xarch_host -fsanitize=address \
 	  -Iinclude -I$(PKG)/csrc -o asan_build/libraytracer_amd.so $(HIP_SRC)
 	$(ASANXX) -O1 -g -std=c++17 -ffp-contract=off -fsanitize=address -fPIC -shared -Iinclude -o asan_build/librt_host.so $(HOST_SRC) -lz -pthread
-	$(ASANXX) -O1 -g -std=c++17 -fsanitize=address -Iinclude -o asan_build/rt_render $(PKG)/host/rt_cli.cpp -Lasan_build -lrt_host -lraytracer_amd \
-	  -Wl,-rpath,'$$ORIGIN' -Wl,-rpath-link,/opt/rocm/lib
+	$(ASANXX) -O1 -g -std=c++17 -pthread -fsanitize=address -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include -o asan_build/rt_render $(PKG)/host/rt_cli.cpp \
+	  -Lasan_build -lrt_host -lraytracer_amd -L/opt/rocm/lib -lamdhip64 -lrccl -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 
 .PHONY: all host hip cli oracle clean microbench asan

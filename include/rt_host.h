@@ -37,6 +37,16 @@ void rth_free_scene(rth_scene* scene);
  * rt_download fills -- as an 8-bit RGBA PNG. */
 int rth_write_png(const char* path, const uint8_t* rgba, int width, int height);
 
+/* Where scanline tile k of an N-GPU job lies in the frame (the layout of rt_download and
+ * rt_bind_frame: RGBA8, row 0 = top scanline): tile k is film rows [k * tile_rows,
+ * min((k + 1) * tile_rows, height)) -- film row 0 is the BOTTOM scanline (raytracer.cpp:153, 225) --
+ * and belongs to rank k % n_ranks (rt_render_tiles(ctx, rank, tile_rows, n_ranks)).  Its rows are
+ * contiguous in the frame: *offset is the byte offset of the tile's topmost row, *bytes its length.
+ * Returns the owning rank, or RT_ERR_ARG when k is not a tile of the frame.  The end-of-frame
+ * exchange sends exactly these spans to rank 0 (no counterpart in the reference, which has one
+ * process and no exchange). */
+int rth_tile_span(int width, int height, int tile_rows, int n_ranks, int k, size_t* offset, size_t* bytes);
+
 const char* rth_last_error(void);
 
 #ifdef __cplusplus

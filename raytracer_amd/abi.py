@@ -76,7 +76,7 @@ class RtStats(C.Structure):
 
 
 HOST_SYMBOLS = ["rth_load_scene", "rth_load_blob", "rth_save_blob", "rth_desc", "rth_free_scene",
-                "rth_write_png", "rth_last_error"]
+                "rth_write_png", "rth_tile_span", "rth_last_error"]
 DEVICE_SYMBOLS = ["rt_upload_scene", "rt_set_option", "rt_render_tile", "rt_render_tiles", "rt_render_tile_noalloc",
                   "rt_bind_frame", "rt_download", "rt_primary_hits", "rt_queue_pixel", "rt_get_stats", "rt_reset_stats", "rt_device_info",
                   "rt_free", "rt_last_error"]
@@ -111,6 +111,8 @@ def host_lib():
         lib.rth_free_scene.restype = None
         lib.rth_write_png.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
         lib.rth_write_png.restype = C.c_int
+        lib.rth_tile_span.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        lib.rth_tile_span.restype = C.c_int
         lib.rth_last_error.argtypes = []
         lib.rth_last_error.restype = C.c_char_p
         _host = lib

@@ -1,29 +1,99 @@
 // Host driver: stands where the reference's main() does (raytracer.cpp:843-868).
 //
-//   rt_render <scene> [out.png] [-w W] [-h H] [-depth D] [-eps E] [-tile ROWS] [-bvh] [-exact] [-stats]
+//   rt_render <scene> [out.png] [-w W] [-h H] [-depth D] [-eps E] [-tile ROWS] [-gpus N] [-bvh] [-exact] [-stats]
 //
 // With no options it does what `./raytracer <scene> [out.png]` does: 1000 x 1000, eps 0.05,
 // depth 6, output.png (raytracer.cpp:847-862).  Parsing goes through the host loader
 // (include/rt_host.h), the trace loop through the C ABI (include/rt_abi.h), the PNG through
 // rth_write_png.  There is no CPU rendering path here: without a GPU the program fails.
+//
+// -gpus N: the frame is cut into interleaved scanline tiles of ROWS rows (default 16); GPU r of N
+// traces tiles r, r + N, r + 2N, ... (rt_render_tiles) into a full-size frame of its own, and one
+// exchange at the end of the frame moves every tile to GPU 0: grouped ncclSend / ncclRecv (RCCL
+// over xGMI) of each tile's rows -- which are contiguous in the frame (rth_tile_span) -- straight
+// into the same rows of GPU 0's frame, no staging copy on either side.  One host thread per GPU,
+// one communicator per GPU from ncclCommInitAll.  The reference has no counterpart: it is one
+// thread on one CPU.
 #include "rt_abi.h"
 #include "rt_host.h"
 
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
+
+namespace {
+
+struct RankResult {
+    int rc = 0;
+    std::string error;
+    rt_stats stats{};
+    double render_s = 0;          // enqueue of the tiles until this rank's part of the exchange has finished
+};
+
+// One GPU's share of an N-GPU frame.  Rank 0 ends up with the whole frame in `image`.
+void run_rank(int rank, int n_ranks, ncclComm_t comm, const rt_scene_desc* desc, int tile_rows, bool bvh, bool exact,
+              std::vector<uint8_t>* image, RankResult* out) {
+    auto fail = [&](const std::string& what) { out->rc = 1; out->error = "GPU " + std::to_string(rank) + ": " + what; };
+    if (hipSetDevice(rank) != hipSuccess) return fail("hipSetDevice failed");
+    const int W = desc->width, H = desc->height;
+    const size_t frame_bytes = (size_t)W * H * 4;
+    rt_ctx* ctx = nullptr;
+    void* frame = nullptr;
+    hipStream_t stream = nullptr;
+    do {
+        if (rt_upload_scene(&ctx, desc)) { fail(rt_last_error()); break; }
+        if (exact && rt_set_option(ctx, RT_OPT_EXACT_ONLY, 1)) { fail(rt_last_error()); break; }
+        if (bvh && rt_set_option(ctx, RT_OPT_USE_BVH, 1)) { fail(rt_last_error()); break; }
+        if (hipMalloc(&frame, frame_bytes) != hipSuccess || hipMemset(frame, 0, frame_bytes) != hipSuccess) { fail("cannot allocate the frame"); break; }
+        if (rt_bind_frame(ctx, frame, frame_bytes)) { fail(rt_last_error()); break; }
+        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { fail("cannot create a stream"); break; }
+        const auto t0 = std::chrono::steady_clock::now();
+        if (rt_render_tiles(ctx, rank, tile_rows, n_ranks, stream)) { fail(rt_last_error()); break; }
+        // the exchange, enqueued behind the tiles on the same stream
+        const int n_tiles = (H + tile_rows - 1) / tile_rows;
+        ncclResult_t nr = ncclGroupStart();
+        for (int k = 0; k < n_tiles && nr == ncclSuccess; k++) {
+            size_t off = 0, bytes = 0;
+            const int owner = rth_tile_span(W, H, tile_rows, n_ranks, k, &off, &bytes);
+            if (owner < 0) { nr = ncclInvalidArgument; break; }
+            if (owner == 0) continue;                                        // already where it belongs
+            if (rank == 0) nr = ncclRecv((char*)frame + off, bytes, ncclUint8, owner, comm, stream);
+            else if (rank == owner) nr = ncclSend((const char*)frame + off, bytes, ncclUint8, 0, comm, stream);
+        }
+        const ncclResult_t ne = ncclGroupEnd();
+        if (nr == ncclSuccess) nr = ne;
+        if (nr != ncclSuccess) { fail(std::string("RCCL exchange: ") + ncclGetErrorString(nr)); break; }
+        if (hipStreamSynchronize(stream) != hipSuccess) { fail("stream synchronisation failed"); break; }
+        out->render_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (rt_get_stats(ctx, &out->stats)) { fail(rt_last_error()); break; }
+        if (rank == 0) {
+            image->resize(frame_bytes);
+            if (hipMemcpy(image->data(), frame, frame_bytes, hipMemcpyDeviceToHost) != hipSuccess) { fail("cannot copy the frame to the host"); break; }
+        }
+    } while (false);
+    if (stream) (void)hipStreamDestroy(stream);
+    if (ctx) rt_free(ctx);
+    if (frame) (void)hipFree(frame);
+}
+
+}  // namespace
 
 int main(int argc, char** argv) {
     if (argc < 2) {
-        fprintf(stderr, "usage: %s <scene> [out.png] [-w W] [-h H] [-depth D] [-eps E] [-tile ROWS] [-bvh] [-exact] [-stats]\n",
+        fprintf(stderr, "usage: %s <scene> [out.png] [-w W] [-h H] [-depth D] [-eps E] [-tile ROWS] [-gpus N] [-bvh] [-exact] [-stats]\n",
                 argv[0]);
         return 2;
     }
     std::string scene = argv[1], out = "output.png";
-    int width = 1000, height = 1000, depth = -1, tile = 0;
+    int width = 1000, height = 1000, depth = -1, tile = 0, gpus = 0;
     float eps = 0.f;
     bool bvh = false, exact = false, stats = false;
     int pos = 0;
@@ -38,12 +108,14 @@ int main(int argc, char** argv) {
         else if (a == "-depth") depth = atoi(need("-depth"));
         else if (a == "-eps") eps = (float)atof(need("-eps"));
         else if (a == "-tile") tile = atoi(need("-tile"));
+        else if (a == "-gpus") gpus = atoi(need("-gpus"));
         else if (a == "-bvh") bvh = true;
         else if (a == "-exact") exact = true;
         else if (a == "-stats") stats = true;
         else if (pos++ == 0) out = a;
         else { fprintf(stderr, "unexpected argument %s\n", a.c_str()); return 2; }
     }
+    if (gpus < 0 || gpus > 64) { fprintf(stderr, "-gpus must be between 1 and 64\n"); return 2; }
     printf("Ray Tracer!\n");
     auto now = []() { return std::chrono::steady_clock::now(); };
     auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(now() - t).count(); };
@@ -54,47 +126,96 @@ int main(int argc, char** argv) {
         return 1;
     }
     const double load_s = since(t_load);
-    auto t_upload = now();
-    rt_ctx* ctx = nullptr;
-    if (rt_upload_scene(&ctx, rth_desc(sc))) {
-        fprintf(stderr, "%s\n", rt_last_error());
-        return 1;
+    std::vector<uint8_t> image;
+    rt_stats st{};
+    double secs = 0, upload_s = 0, bvh_s = 0;
+    int status = 0;
+
+    if (gpus >= 1) {
+        // ---- N GPUs: one host thread and one communicator per GPU ----
+        int n_dev = 0;
+        if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < gpus) {
+            fprintf(stderr, "-gpus %d: only %d HIP device(s) visible\n", gpus, n_dev);
+            rth_free_scene(sc);
+            return 1;
+        }
+        std::vector<int> devs(gpus);
+        for (int g = 0; g < gpus; g++) devs[g] = g;
+        std::vector<ncclComm_t> comms(gpus);
+        ncclResult_t nr = ncclCommInitAll(comms.data(), gpus, devs.data());
+        if (nr != ncclSuccess) {
+            fprintf(stderr, "ncclCommInitAll: %s\n", ncclGetErrorString(nr));
+            rth_free_scene(sc);
+            return 1;
+        }
+        printf("Rendering Scene...\n");
+        const int rows = tile > 0 ? tile : 16;
+        std::vector<RankResult> results(gpus);
+        auto t0 = now();
+        {
+            std::vector<std::thread> pool;
+            for (int g = 0; g < gpus; g++)
+                pool.emplace_back(run_rank, g, gpus, comms[g], rth_desc(sc), rows, bvh, exact, &image, &results[g]);
+            for (auto& th : pool) th.join();
+        }
+        const double wall = since(t0);         // upload, render, exchange and the copy to the host, all ranks
+        for (int g = 0; g < gpus; g++) (void)ncclCommDestroy(comms[g]);
+        for (int g = 0; g < gpus; g++) {
+            if (results[g].rc) { fprintf(stderr, "%s\n", results[g].error.c_str()); status = 1; }
+            secs = std::max(secs, results[g].render_s);
+            st.rays_primary += results[g].stats.rays_primary; st.rays_reflect += results[g].stats.rays_reflect;
+            st.rays_shadow += results[g].stats.rays_shadow; st.hits += results[g].stats.hits;
+        }
+        st.n_triangles = results[0].stats.n_triangles; st.n_spheres = results[0].stats.n_spheres;
+        upload_s = wall - secs;
+    } else {
+        // ---- one GPU, the current device ----
+        auto t_upload = now();
+        rt_ctx* ctx = nullptr;
+        if (rt_upload_scene(&ctx, rth_desc(sc))) {
+            fprintf(stderr, "%s\n", rt_last_error());
+            rth_free_scene(sc);
+            return 1;
+        }
+        upload_s = since(t_upload);
+        auto t_bvh = now();
+        if ((exact && rt_set_option(ctx, RT_OPT_EXACT_ONLY, 1)) || (bvh && rt_set_option(ctx, RT_OPT_USE_BVH, 1))) {
+            fprintf(stderr, "%s\n", rt_last_error());
+            rt_free(ctx);
+            rth_free_scene(sc);
+            return 1;
+        }
+        bvh_s = since(t_bvh);   // the build is synchronous
+        printf("Rendering Scene...\n");
+        auto t0 = now();
+        int rc = tile > 0 ? rt_render_tiles(ctx, 0, tile, 1, nullptr) : rt_render_tile(ctx, 0, height, nullptr);
+        image.resize((size_t)width * height * 4);
+        if (!rc) rc = rt_download(ctx, image.data(), image.size());
+        secs = since(t0);
+        if (rc) { fprintf(stderr, "%s\n", rt_last_error()); status = 1; }
+        if (!rc && stats && rt_get_stats(ctx, &st)) { fprintf(stderr, "%s\n", rt_last_error()); status = 1; }
+        rt_free(ctx);
     }
-    const double upload_s = since(t_upload);
-    if (exact && rt_set_option(ctx, RT_OPT_EXACT_ONLY, 1)) { fprintf(stderr, "%s\n", rt_last_error()); return 1; }
-    auto t_bvh = now();
-    if (bvh && rt_set_option(ctx, RT_OPT_USE_BVH, 1)) { fprintf(stderr, "%s\n", rt_last_error()); return 1; }
-    const double bvh_s = since(t_bvh);   // the build is synchronous
-    printf("Rendering Scene...\n");
-    auto t0 = std::chrono::steady_clock::now();
-    int rc = tile > 0 ? rt_render_tiles(ctx, 0, tile, 1, nullptr) : rt_render_tile(ctx, 0, height, nullptr);
-    std::vector<uint8_t> image((size_t)width * height * 4);
-    if (!rc) rc = rt_download(ctx, image.data(), image.size());
-    double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (rc) { fprintf(stderr, "%s\n", rt_last_error()); return 1; }
+    if (status) { rth_free_scene(sc); return 1; }
     printf("Scene render completed.\n");
     if (stats) {
-        rt_stats st;
-        if (!rt_get_stats(ctx, &st)) {
-            unsigned long long rays = st.rays_primary + st.rays_reflect + st.rays_shadow;
-            printf("{\"render_s\": %.6f, \"rays_primary\": %llu, \"rays_reflect\": %llu, \"rays_shadow\": %llu, \"hits\": %llu, "
-                   "\"Mrays_per_s\": %.3f, \"triangles\": %d, \"spheres\": %d}\n",
-                   secs, (unsigned long long)st.rays_primary, (unsigned long long)st.rays_reflect,
-                   (unsigned long long)st.rays_shadow, (unsigned long long)st.hits, rays / secs / 1e6, st.n_triangles,
-                   st.n_spheres);
-        }
+        unsigned long long rays = st.rays_primary + st.rays_reflect + st.rays_shadow;
+        printf("{\"render_s\": %.6f, \"gpus\": %d, \"rays_primary\": %llu, \"rays_reflect\": %llu, \"rays_shadow\": %llu, \"hits\": %llu, "
+               "\"Mrays_per_s\": %.3f, \"triangles\": %d, \"spheres\": %d}\n",
+               secs, gpus >= 1 ? gpus : 1, (unsigned long long)st.rays_primary, (unsigned long long)st.rays_reflect,
+               (unsigned long long)st.rays_shadow, (unsigned long long)st.hits, rays / secs / 1e6, st.n_triangles, st.n_spheres);
     }
     printf("Writing to file...\n");
     auto t_png = now();
     if (rth_write_png(out.c_str(), image.data(), width, height)) {
         fprintf(stderr, "cannot write %s\n", out.c_str());
+        rth_free_scene(sc);
         return 1;
     }
     printf("Image saved as %s.\n", out.c_str());
-    if (stats)   // render_s above covers the trace and the download of the frame
+    if (stats)   // render_s above covers the trace and the download of the frame (N GPUs: the trace and the exchange)
         printf("{\"load_s\": %.6f, \"upload_s\": %.6f, \"bvh_build_s\": %.6f, \"png_s\": %.6f}\n", load_s, upload_s, bvh_s,
                since(t_png));
-    rt_free(ctx);
     rth_free_scene(sc);
     return 0;
 }

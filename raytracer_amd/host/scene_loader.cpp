@@ -656,6 +656,18 @@ int rth_load_blob(rth_scene** out, const char* path) {
     return 0;
 }
 
+int rth_tile_span(int width, int height, int tile_rows, int n_ranks, int k, size_t* offset, size_t* bytes) {
+    if (width <= 0 || height <= 0 || tile_rows <= 0 || n_ranks <= 0 || k < 0 || !offset || !bytes)
+        return fail(RT_ERR_ARG, "rth_tile_span: bad argument");
+    const long long y0 = (long long)k * tile_rows;
+    if (y0 >= height) return fail(RT_ERR_ARG, "rth_tile_span: no such tile");
+    const long long y1 = std::min<long long>(y0 + tile_rows, height);
+    // film row y is frame row height - 1 - y: the tile's top frame row is that of its last film row
+    *offset = (size_t)(height - y1) * (size_t)width * 4;
+    *bytes = (size_t)(y1 - y0) * (size_t)width * 4;
+    return k % n_ranks;
+}
+
 const rt_scene_desc* rth_desc(const rth_scene* s) { return s ? &s->d : nullptr; }
 void rth_free_scene(rth_scene* s) { delete s; }
 const char* rth_last_error(void) { return g_err.c_str(); }

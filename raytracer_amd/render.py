@@ -116,57 +116,59 @@ def tiles_of_rank(height, tile_rows, rank, world):
     return [(k * tile_rows, min((k + 1) * tile_rows, height)) for k in range(rank, n_tiles, world)]
 
 
-def pack_rows(frame, height, tile_rows, rank, world):
-    """Gather the rows a rank rendered into one contiguous buffer (frame is [H, W, 4],
-    row 0 = top scanline, so film row y is frame row H-1-y).  Works on numpy arrays and
-    torch tensors alike; every rank's buffer is padded to the same number of rows."""
-    n_tiles = (height + tile_rows - 1) // tile_rows
-    max_tiles = (n_tiles + world - 1) // world
-    rows = []
-    for y0, y1 in tiles_of_rank(height, tile_rows, rank, world):
-        rows.extend(range(height - 1 - y0, height - 1 - y1, -1))
-    return rows, max_tiles * tile_rows
+def tile_spans(width, height, tile_rows, world):
+    """[(owner rank, first frame row, last frame row + 1)] of every tile, from the host library's
+    rth_tile_span (the same function the C++ driver's exchange uses): a tile's rows are contiguous in
+    the frame (row 0 = top scanline, so film row y is frame row height - 1 - y)."""
+    lib = abi.host_lib()
+    out = []
+    off, nbytes = C.c_size_t(), C.c_size_t()
+    row_bytes = width * 4
+    for k in range((height + tile_rows - 1) // tile_rows):
+        owner = lib.rth_tile_span(width, height, tile_rows, world, k, C.byref(off), C.byref(nbytes))
+        if owner < 0:
+            raise DeviceError(f"rth_tile_span failed: {lib.rth_last_error().decode()}")
+        out.append((owner, off.value // row_bytes, (off.value + nbytes.value) // row_bytes))
+    return out
 
 
 class TileGather:
-    """End-of-frame exchange, set up once per (frame size, tiling, rank): every rank sends the
-    rows of its tiles to rank 0, which writes them into its frame.  The collective is
-    torch.distributed.gather (RCCL over xGMI on GPUs, gloo on CPU).  Index tensors and
-    staging buffers are built here, not per frame.  `host_staging` sends the packed rows
-    through host memory (for a backend that has no device-memory gather, i.e. gloo with the
-    frame on a GPU)."""
+    """End-of-frame exchange, set up once per (frame size, tiling, rank): every rank sends the rows
+    of each of its tiles -- a contiguous slice of its frame -- to rank 0, which receives them straight
+    into the same rows of its own frame: one batch of point-to-point operations
+    (torch.distributed.batch_isend_irecv: grouped ncclSend / ncclRecv over xGMI with the nccl = RCCL
+    backend, gloo on CPU), no packing, no staging copy, no scatter afterwards.  `host_staging` moves the
+    slices through host memory (for a backend without device-memory transfers, i.e. gloo with the frame
+    on a GPU: a rehearsal of the N-rank flow on a box with fewer GPUs than ranks)."""
 
     def __init__(self, height, width, tile_rows, rank, world, device, dist=None, torch=None, host_staging=False):
         self.rank, self.world, self.dist, self.torch = rank, world, dist, torch
         self.host_staging = host_staging
-        rows, padded = pack_rows(None, height, tile_rows, rank, world)
-        self.n_rows = len(rows)
-        self.idx = torch.as_tensor(rows, dtype=torch.long, device=device)
-        self.send = torch.zeros((padded, width, 4), dtype=torch.uint8, device=device)
-        self.recv = None
-        self.peer_idx = {}
-        coll_device = "cpu" if host_staging else device
-        if rank == 0 and world > 1:
-            self.recv = [torch.empty((padded, width, 4), dtype=torch.uint8, device=coll_device) for _ in range(world)]
-            for r in range(1, world):
-                rrows, _ = pack_rows(None, height, tile_rows, r, world)
-                self.peer_idx[r] = torch.as_tensor(rrows, dtype=torch.long, device=device)
+        self.spans = [(o, a, b) for o, a, b in tile_spans(width, height, tile_rows, world) if o != 0] if world > 1 else []
 
     def __call__(self, frame):
         if self.world == 1:
             return frame
-        torch = self.torch
-        if self.n_rows:
-            torch.index_select(frame, 0, self.idx, out=self.send[: self.n_rows])
-        self.dist.gather(self.send.cpu() if self.host_staging else self.send, self.recv, dst=0)
-        if self.rank == 0:
-            for r, ridx in self.peer_idx.items():
-                if ridx.numel():
-                    frame.index_copy_(0, ridx, self.recv[r][: ridx.numel()].to(frame.device))
+        dist = self.dist
+        ops, landed = [], []
+        for owner, a, b in self.spans:
+            if self.rank == 0:
+                buf = frame[a:b]
+                if self.host_staging:
+                    buf = self.torch.empty(buf.shape, dtype=buf.dtype, device="cpu")
+                    landed.append((a, b, buf))
+                ops.append(dist.P2POp(dist.irecv, buf, owner))
+            elif self.rank == owner:
+                ops.append(dist.P2POp(dist.isend, frame[a:b].cpu() if self.host_staging else frame[a:b], 0))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for a, b, buf in landed:
+            frame[a:b].copy_(buf)
         return frame
 
 
 def gather_frame(renderer, frame, tile_rows, rank, world, dist=None, torch=None):
-    """One-shot form of TileGather (builds the index tensors on every call)."""
+    """One-shot form of TileGather."""
     g = TileGather(frame.shape[0], frame.shape[1], tile_rows, rank, world, frame.device, dist=dist, torch=torch)
     return g(frame)

@@ -383,3 +383,25 @@ def test_cli_driver_writes_the_reference_image(tmp_path):
     assert res.returncode == 0, res.stderr
     want = oracle_api.load_png(os.path.join(ROOT, "tests", "golden", "images", "image-03.png"))
     assert_parity(oracle_api.load_png(str(out2)), want, max_diff_pixels=3)
+
+
+def test_cli_driver_n_gpu_path_with_one_gpu(tmp_path):
+    """`rt_render -gpus 1`: the N-GPU path of the C++ driver (ncclCommInitAll, one host thread per GPU,
+    interleaved tiles into a caller-owned frame, the grouped ncclSend / ncclRecv exchange -- empty for one
+    rank) must write the picture of the single-GPU path."""
+    import subprocess
+    exe = os.path.join(ROOT, "raytracer_amd", "rt_render")
+    assert os.path.exists(exe), "run `make cli`"
+    scene = os.path.join(ROOT, "scenes", "mixed_xf.scene")
+    one, multi = tmp_path / "one.png", tmp_path / "multi.png"
+    common = ["-w", "160", "-h", "117", "-depth", "4"]           # 117 rows: the last 8-row tile is clipped
+    res = subprocess.run([exe, scene, str(one)] + common, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    res = subprocess.run([exe, scene, str(multi), "-gpus", "1", "-tile", "8", "-stats"] + common, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    assert '"gpus": 1' in res.stdout
+    assert np.array_equal(oracle_api.load_png(str(one)), oracle_api.load_png(str(multi)))
+    # more GPUs than the box has: a clean error
+    res = subprocess.run([exe, scene, str(multi), "-gpus", "63"] + common, capture_output=True, text=True)
+    assert res.returncode == 1 and "visible" in res.stderr
+

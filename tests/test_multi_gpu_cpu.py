@@ -1,9 +1,11 @@
-"""The N-GPU tile exchange on CPU: two gloo ranks, each owning the interleaved scanline
-tiles rt_render_tiles would give it, gather to rank 0 through raytracer_amd.render.gather_frame.
+"""The N-GPU tile exchange on CPU: gloo ranks, each owning the interleaved scanline tiles
+rt_render_tiles would give it, send their tiles to rank 0 through raytracer_amd.render.gather_frame
+(point-to-point sends of each tile's rows straight into rank 0's frame -- the layout the C++ driver's
+grouped ncclSend / ncclRecv uses, both from rth_tile_span).
 
 No pixel is traced here (the trace loop has no CPU path): every rank fills the rows it owns
-with a rank- and row-coded pattern, so the test checks exactly the exchange -- which rows go
-where, the padding of unequal tile counts, and the clipped last tile."""
+with a row-coded pattern, so the test checks exactly the exchange -- which rows go where,
+unequal tile counts per rank, and the clipped last tile."""
 import os
 import socket
 import sys
@@ -17,7 +19,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from raytracer_amd.render import gather_frame, pack_rows, tiles_of_rank  # noqa: E402
+from raytracer_amd.render import gather_frame, tile_spans, tiles_of_rank  # noqa: E402
 
 
 def _free_port():
@@ -51,7 +53,7 @@ def _worker(rank, world, port, H, W, tile_rows, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("H,W,tile_rows,world", [(70, 33, 8, 2), (64, 16, 16, 2), (37, 9, 5, 3)])
+@pytest.mark.parametrize("H,W,tile_rows,world", [(70, 33, 8, 2), (64, 16, 16, 2), (37, 9, 5, 3), (50, 7, 16, 4)])
 def test_gather_rebuilds_the_frame(tmp_path, H, W, tile_rows, world):
     out = str(tmp_path / "frame.npy")
     mp.spawn(_worker, args=(world, _free_port(), H, W, tile_rows, out), nprocs=world, join=True)
@@ -66,6 +68,27 @@ def test_tile_ownership_is_a_partition():
         for rank in range(world):
             for y0, y1 in tiles_of_rank(H, T, rank, world):
                 seen[y0:y1] += 1
-            rows, padded = pack_rows(None, H, T, rank, world)
-            assert len(rows) <= padded and padded % T == 0
         assert (seen == 1).all()
+
+
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
+@pytest.mark.parametrize("H,W,T", [(2160, 3840, 16), (4320, 7680, 16), (1000, 1000, 16), (37, 9, 5), (50, 7, 16), (16, 4, 16), (1, 1, 16)])
+def test_tile_spans_map_tiles_to_frame_rows(world, H, W, T):
+    """rth_tile_span (what the C++ driver's ncclSend / ncclRecv exchange and TileGather both use) against
+    the definition: tile k = film rows [kT, min((k+1)T, H)) of rank k % N, film row y = frame row H-1-y.
+    Ragged heights included: the last tile is clipped, ranks own unequal numbers of tiles."""
+    spans = tile_spans(W, H, T, world)
+    assert len(spans) == (H + T - 1) // T
+    covered = np.zeros(H, dtype=np.int32)
+    for k, (owner, a, b) in enumerate(spans):
+        y0, y1 = k * T, min((k + 1) * T, H)
+        assert owner == k % world
+        assert (a, b) == (H - y1, H - y0)                      # contiguous frame rows, top row first
+        assert (y0, y1) in tiles_of_rank(H, T, owner, world)   # the rows rt_render_tiles(rank = owner) traces
+        covered[a:b] += 1
+    assert (covered == 1).all()
+    # no such tile: an error, not a span
+    import ctypes as C
+    from raytracer_amd import abi
+    off, nb = C.c_size_t(), C.c_size_t()
+    assert abi.host_lib().rth_tile_span(W, H, T, world, len(spans), C.byref(off), C.byref(nb)) < 0
