@@ -89,7 +89,11 @@ typedef enum rt_option {
     RT_OPT_PROFILE = 2,      /* 1: bracket every trace-kernel launch with HIP events; the sums
                                 appear in rt_stats */
     RT_OPT_PASS_PIXELS = 3,  /* pixels traced per internal pass (bounds the workspace) */
-    RT_OPT_USE_BVH = 4,      /* 1: build (once) and use the LBVH in place of the brute-force triangle scan */
+    RT_OPT_USE_BVH = 4,      /* 1: build (once) and use the LBVH in place of the brute-force triangle scan.  Same
+                                frames as the scan EXCEPT for the in-plane-origin branch of Triangle::intersection
+                                (raytracer.cpp:319-321: a ray that starts exactly in a triangle's plane and grazes it
+                                "hits" at its own origin wherever the triangle is), which no box hierarchy can find;
+                                rt_stats.in_plane_origin_hits of a brute-force render says whether a scene has any */
     RT_OPT_FILTER_FORM = 5,  /* form of the FP32 candidate filter: 0 = chosen from the scene when it was
                                 uploaded (default), 1 = static worst-case margins (cheapest test), 2 = per-test
                                 margins (one more instruction per test; for meshes of triangles that are
@@ -218,6 +222,20 @@ int rt_download(rt_ctx* ctx, uint8_t* rgba, size_t bytes);
  * the options (filter form, LBVH, exact-only).  Blocks; runs on the default stream; leaves those
  * rows of the frame black. */
 int rt_primary_hits(rt_ctx* ctx, int y0, int rows, uint64_t* keys, size_t count);
+
+/* Known-answer hook beyond the camera rays, for every pixel of film rows [y0, y0 + rows), row-major from
+ * row y0; any output pointer may be NULL.  With the camera ray's nearest hit (rt_primary_hits):
+ *   point[3], refl[3]   the hit point and the reflected ray's unit direction (Scene::traceRay,
+ *                       raytracer.cpp:531-538); zeros where the camera ray misses;
+ *   occluded[words]     bit l of word l / 32: the shadow ray from the hit point towards light l is blocked
+ *                       (Scene::traceShadowRay, raytracer.cpp:551-558, 565-567); words = max(1, (n_lights + 31) / 32);
+ *   keys1               the nearest hit of the reflected ray (the object loop of the recursive traceRay call,
+ *                       raytracer.cpp:543, 516-529), encoded as rt_primary_hits' keys; the miss key where
+ *                       there is no reflected ray.
+ * `count` is the capacity of the arrays in pixels.  Honours the options; blocks; default stream; leaves
+ * those rows of the frame black. */
+int rt_bounce_probe(rt_ctx* ctx, int y0, int rows, double* point, double* refl, uint32_t* occluded, uint64_t* keys1,
+                    size_t count);
 
 /* Test hook, host arithmetic only (needs no GPU and no ctx): the pixel that index p of the ray
  * queue of a pass stands for.  A pass of `rows` film rows of `width` pixels numbers its camera rays

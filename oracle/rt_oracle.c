@@ -340,6 +340,44 @@ int rto_trace(const rt_scene_desc* s, const double* orig, const double* dir, int
     return 0;
 }
 
+/* One bounce of n rays, for per-ray known answers beyond the camera rays: the nearest hit
+ * (raytracer.cpp:515-530), the hit point and the reflected ray's direction (raytracer.cpp:531-538), and
+ * per light whether the shadow ray from the hit point is blocked (raytracer.cpp:565-567, 551-558).
+ * hit[k] = object index or -1; point, refl: [n][3]; occluded: [n][words] with bit l of word l / 32 set when
+ * light l is blocked, words = (n_lights + 31) / 32 (at least 1). */
+int rto_bounce(const rt_scene_desc* s, const double* orig, const double* dir, int n,
+               int32_t* hit, double* point, double* refl_out, uint32_t* occluded) {
+    const int words = s->n_lights > 0 ? (s->n_lights + 31) / 32 : 1;
+    for (int k = 0; k < n; k++) {
+        rto_hit h = closest_hit(s, v3_ptr(orig + 3 * k), v3_ptr(dir + 3 * k), NULL);
+        hit[k] = h.hit;
+        for (int w = 0; w < words; w++) occluded[(size_t)k * words + w] = 0u;
+        for (int a = 0; a < 3; a++) { point[3 * k + a] = 0.0; refl_out[3 * k + a] = 0.0; }
+        if (h.hit < 0) continue;
+        int i = h.hit;
+        const rt_transform* T = &s->transforms[s->obj_transform[i]];
+        const double* g = s->obj_geom + 9 * (size_t)i;
+        v3 local = m4_point(T->inv, h.point);
+        v3 normal;
+        if (s->obj_kind[i] == 0)
+            normal = tri_normal(g, s->obj_normals ? s->obj_normals + 9 * (size_t)i : g, s->obj_interp[i], local);
+        else
+            normal = v3_sub(local, v3_ptr(g));
+        normal = m4_dir(T->inv_t, normal);
+        normal = v3_normalize(normal);
+        v3 refl = v3_sub(h.ray_vec, v3_scale(normal, 2 * v3_dot(h.ray_vec, normal)));
+        refl = v3_normalize(refl);
+        point[3 * k] = h.point.x; point[3 * k + 1] = h.point.y; point[3 * k + 2] = h.point.z;
+        refl_out[3 * k] = refl.x; refl_out[3 * k + 1] = refl.y; refl_out[3 * k + 2] = refl.z;
+        for (int l = 0; l < s->n_lights; l++) {
+            const rt_light* L = &s->lights[l];
+            v3 lvec = L->is_point ? v3_sub(v3_ptr(L->pos), h.point) : v3_neg(v3_ptr(L->pos));
+            if (trace_shadow(s, h.point, v3_normalize(lvec), i, NULL)) occluded[(size_t)k * words + (l >> 5)] |= 1u << (l & 31);
+        }
+    }
+    return 0;
+}
+
 /* Camera rays of film row y: orig/dir [width][3]. */
 int rto_camera_row(const rt_scene_desc* s, int y, double* orig, double* dir) {
     for (int x = 0; x < s->width; x++) {

@@ -78,7 +78,7 @@ class RtStats(C.Structure):
 HOST_SYMBOLS = ["rth_load_scene", "rth_load_blob", "rth_save_blob", "rth_desc", "rth_free_scene",
                 "rth_write_png", "rth_tile_span", "rth_last_error"]
 DEVICE_SYMBOLS = ["rt_upload_scene", "rt_set_option", "rt_render_tile", "rt_render_tiles", "rt_render_tile_noalloc",
-                  "rt_bind_frame", "rt_download", "rt_primary_hits", "rt_queue_pixel", "rt_get_stats", "rt_reset_stats", "rt_device_info",
+                  "rt_bind_frame", "rt_download", "rt_primary_hits", "rt_bounce_probe", "rt_queue_pixel", "rt_get_stats", "rt_reset_stats", "rt_device_info",
                   "rt_free", "rt_last_error"]
 
 _host = None
@@ -143,6 +143,8 @@ def device_lib():
         lib.rt_download.restype = C.c_int
         lib.rt_primary_hits.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         lib.rt_primary_hits.restype = C.c_int
+        lib.rt_bounce_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.rt_bounce_probe.restype = C.c_int
         lib.rt_queue_pixel.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         lib.rt_queue_pixel.restype = C.c_int
         lib.rt_get_stats.argtypes = [C.c_void_p, C.POINTER(RtStats)]

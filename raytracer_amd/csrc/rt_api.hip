@@ -1629,6 +1629,99 @@ int rt_primary_hits(rt_ctx* c, int y0, int rows, uint64_t* keys, size_t count) {
     RT_GUARD_END("rt_primary_hits")
 }
 
+int rt_bounce_probe(rt_ctx* c, int y0, int rows, double* point, double* refl, uint32_t* occluded, uint64_t* keys1, size_t count) {
+    if (!c) return fail(RT_ERR_ARG, "rt_bounce_probe: null ctx");
+    if (rows <= 0 || y0 < 0 || (long long)y0 + rows > c->hs.height)
+        return fail(RT_ERR_RANGE, "rt_bounce_probe: rows outside the frame");
+    const int W = c->hs.width;
+    if (count < (size_t)rows * W) return fail(RT_ERR_RANGE, "rt_bounce_probe: buffers too small");
+    RT_GUARD_BEGIN
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());          // renders still in flight on other streams use the same workspace
+    int rc = ensure_workspace(c);
+    if (rc) return rc;
+    const Workspace& ws = c->ws;
+    if (ws.levels < 2 && keys1) return fail(RT_ERR_STATE, "rt_bounce_probe: the scene's depth is 0, there is no reflected ray");
+    const int rows_per_pass = (int)(ws.cap / W);
+    const int words = ws.occl_words;
+    hipStream_t st = nullptr;
+    const DevScene* dsc = c->d_scene.p;
+    const size_t n_px = (size_t)rows * W;
+    if (point) std::fill(point, point + 3 * n_px, 0.0);
+    if (refl) std::fill(refl, refl + 3 * n_px, 0.0);
+    if (occluded) std::fill(occluded, occluded + (size_t)words * n_px, 0u);
+    if (keys1) std::fill(keys1, keys1 + n_px, (uint64_t)RT_MISS_KEY);
+    std::vector<int32_t> parent;
+    std::vector<double> rays;
+    std::vector<uint32_t> occl;
+    std::vector<uint64_t> k1;
+    for (int q0 = 0; q0 < rows; q0 += rows_per_pass) {
+        const int nrows = std::min(rows_per_pass, rows - q0);
+        const int n_pix = nrows * W;
+        PassDesc pd{y0, rows, rows, q0};
+        HIP_TRY(hipMemsetAsync(ws.counts, 0, (ws.levels + 2) * sizeof(uint32_t), st));
+        RayQueue q[2] = {queue_of(ws.rayq[0], ws.cap), queue_of(ws.rayq[1], ws.cap)};
+        hipLaunchKernelGGL(k_primary, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, dsc, pd, n_pix, q[0], ws.keys[0],
+                           ws.pixel_of_ray, c->frame, ws.counts);
+        HIP_TRY(hipGetLastError());
+        TraceArgs ta{};
+        ta.rays = q[0]; ta.n_items = ws.counts; ta.keys = ws.keys[0]; ta.occl_words = words;
+        rc = launch_trace<0>(c, ws, ta, st, (size_t)n_pix, true);
+        if (rc) return rc;
+        LevelStore lvl = level_of(ws, 0);
+        double* ab = ws.aux[0];
+        HitAux aux;
+        aux.nx = ab; aux.ny = ab + ws.cap; aux.nz = ab + 2 * ws.cap;
+        aux.vx = ab + 3 * ws.cap; aux.vy = ab + 4 * ws.cap; aux.vz = ab + 5 * ws.cap;
+        HitArgs ha{};
+        ha.sc = dsc; ha.cur = q[0]; ha.next = q[1]; ha.keys = ws.keys[0]; ha.next_keys = ws.keys[1];
+        ha.n_rays = ws.counts; ha.hit_offsets = ws.hit_offsets; ha.lvl = lvl; ha.aux = aux;
+        ha.occluded = ws.occluded[0]; ha.occl_words = words;
+        hipLaunchKernelGGL(k_hit_offsets, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, (const unsigned long long*)ws.keys[0],
+                           (const uint32_t*)ws.counts, ws.hit_offsets, ws.counts + 1);
+        hipLaunchKernelGGL(k_hit, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, ha);
+        HIP_TRY(hipGetLastError());
+        if (c->hs.n_lights > 0) {
+            TraceArgs sa{};
+            sa.rays = q[1]; sa.n_items = ws.counts + 1; sa.source_obj = lvl.obj;
+            sa.occluded = ws.occluded[0]; sa.occl_words = words;
+            rc = launch_trace<1>(c, ws, sa, st, (size_t)n_pix * (size_t)std::max(1, c->hs.n_lights));
+            if (rc) return rc;
+        }
+        if (keys1) {
+            TraceArgs tb{};
+            tb.rays = q[1]; tb.n_items = ws.counts + 1; tb.keys = ws.keys[1]; tb.occl_words = words;
+            rc = launch_trace<0>(c, ws, tb, st, (size_t)n_pix, false);
+            if (rc) return rc;
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+        uint32_t n_hits = 0;
+        HIP_TRY(hipMemcpy(&n_hits, ws.counts + 1, sizeof n_hits, hipMemcpyDeviceToHost));
+        if (n_hits > (uint32_t)n_pix) return fail(RT_ERR_DEVICE, "rt_bounce_probe: hit count out of range");
+        parent.resize(n_hits); rays.resize(6 * (size_t)n_hits); occl.resize((size_t)words * n_hits); k1.resize(n_hits);
+        if (n_hits) {
+            HIP_TRY(hipMemcpy(parent.data(), lvl.parent, n_hits * sizeof(int32_t), hipMemcpyDeviceToHost));
+            for (int a = 0; a < 6; a++)
+                HIP_TRY(hipMemcpy(rays.data() + (size_t)a * n_hits, ws.rayq[1] + (size_t)a * ws.cap, n_hits * sizeof(double), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(occl.data(), ws.occluded[0], (size_t)words * n_hits * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            if (keys1) HIP_TRY(hipMemcpy(k1.data(), ws.keys[1], n_hits * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        }
+        for (uint32_t h = 0; h < n_hits; h++) {
+            int row, x;
+            queue_pixel(parent[h], W, nrows, &row, &x);       // the queue is in tile order; the caller's arrays in scanline order
+            const size_t px = (size_t)(q0 + row) * W + x;
+            for (int a = 0; a < 3; a++) {
+                if (point) point[3 * px + a] = rays[(size_t)a * n_hits + h];
+                if (refl) refl[3 * px + a] = rays[(size_t)(3 + a) * n_hits + h];
+            }
+            if (occluded) for (int w = 0; w < words; w++) occluded[px * words + w] = occl[(size_t)h * words + w];
+            if (keys1) keys1[px] = k1[h];
+        }
+    }
+    return 0;
+    RT_GUARD_END("rt_bounce_probe")
+}
+
 int rt_queue_pixel(int p, int width, int rows, int* row, int* x) {
     if (!row || !x) return fail(RT_ERR_ARG, "rt_queue_pixel: null argument");
     if (width <= 0 || rows <= 0 || p < 0 || (long long)p >= (long long)width * rows)

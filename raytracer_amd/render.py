@@ -83,6 +83,25 @@ class Renderer:
         d = (keys >> np.uint64(32)).astype(np.uint32).view(np.float32)
         return obj.astype(np.int32), d
 
+    def bounce_probe(self, n_lights, y0=0, rows=None):
+        """Per pixel of film rows [y0, y0 + rows): the camera ray's hit point, the reflected direction, the
+        occlusion words of the hit's shadow rays, and (object index or -1, metric d) of the reflected ray's
+        nearest hit."""
+        rows = self.height - y0 if rows is None else rows
+        words = max(1, (n_lights + 31) // 32)
+        n = rows * self.width
+        point = np.zeros((rows, self.width, 3)); refl = np.zeros((rows, self.width, 3))
+        occl = np.zeros((rows, self.width, words), dtype=np.uint32)
+        keys = np.empty((rows, self.width), dtype=np.uint64)
+        _check(self._lib, self._lib.rt_bounce_probe(self._ctx, int(y0), int(rows), point.ctypes.data_as(C.c_void_p),
+                                                    refl.ctypes.data_as(C.c_void_p), occl.ctypes.data_as(C.c_void_p),
+                                                    keys.ctypes.data_as(C.c_void_p), n), "rt_bounce_probe")
+        miss = keys == np.uint64(0x7F7FFFFFFFFFFFFF)
+        obj = (keys & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        obj[miss] = -1
+        d = (keys >> np.uint64(32)).astype(np.uint32).view(np.float32)
+        return point, refl, occl, obj.astype(np.int32), d
+
     def stats(self):
         st = abi.RtStats()
         _check(self._lib, self._lib.rt_get_stats(self._ctx, C.byref(st)), "rt_get_stats")

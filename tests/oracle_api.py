@@ -28,6 +28,7 @@ class Oracle:
         self.lib.rto_occluded.restype = C.c_int
         self.lib.rto_trace.restype = C.c_int
         self.lib.rto_camera_row.restype = C.c_int
+        self.lib.rto_bounce.restype = C.c_int
 
     def render(self, scene, y0=0, y1=None, threads=8):
         """Returns (rgba[H, W, 4] uint8 in Film::writeFile layout, counters dict)."""
@@ -55,6 +56,39 @@ class Oracle:
                              C.c_int(n), hit.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p),
                              d.ctypes.data_as(C.c_void_p), pt.ctypes.data_as(C.c_void_p))
         return hit, t, d, pt
+
+
+    def _bounce(self, scene, orig, dirs):
+        n = len(orig)
+        words = max(1, (scene.desc.n_lights + 31) // 32)
+        orig = np.ascontiguousarray(orig, dtype=np.float64); dirs = np.ascontiguousarray(dirs, dtype=np.float64)
+        hit = np.zeros(n, dtype=np.int32); pt = np.zeros((n, 3)); refl = np.zeros((n, 3))
+        occl = np.zeros((n, words), dtype=np.uint32)
+        self.lib.rto_bounce(scene.desc_ptr, orig.ctypes.data_as(C.c_void_p), dirs.ctypes.data_as(C.c_void_p), C.c_int(n),
+                            hit.ctypes.data_as(C.c_void_p), pt.ctypes.data_as(C.c_void_p), refl.ctypes.data_as(C.c_void_p),
+                            occl.ctypes.data_as(C.c_void_p))
+        return hit, pt, refl, occl
+
+    def bounce(self, scene, orig, dirs):
+        """One bounce: (hit index or -1, hit point, reflected direction, occlusion words per light) per ray."""
+        return self._bounce(scene, orig, dirs)
+
+    def occluded(self, scene, orig, dirs, source):
+        n = len(orig)
+        orig = np.ascontiguousarray(orig, dtype=np.float64); dirs = np.ascontiguousarray(dirs, dtype=np.float64)
+        source = np.ascontiguousarray(source, dtype=np.int32)
+        out = np.zeros(n, dtype=np.int32)
+        self.lib.rto_occluded(scene.desc_ptr, orig.ctypes.data_as(C.c_void_p), dirs.ctypes.data_as(C.c_void_p),
+                              source.ctypes.data_as(C.c_void_p), C.c_int(n), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def trace(self, scene, orig, dirs, depth):
+        n = len(orig)
+        orig = np.ascontiguousarray(orig, dtype=np.float64); dirs = np.ascontiguousarray(dirs, dtype=np.float64)
+        rgb = np.zeros((n, 3))
+        self.lib.rto_trace(scene.desc_ptr, orig.ctypes.data_as(C.c_void_p), dirs.ctypes.data_as(C.c_void_p), C.c_int(n),
+                           C.c_int(depth), rgb.ctypes.data_as(C.c_void_p))
+        return rgb
 
 
 def have_reference_binary():

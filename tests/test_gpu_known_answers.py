@@ -68,3 +68,120 @@ def test_rows_and_passes_of_the_hook():
     r.close()
     assert np.array_equal(part_obj, full_obj[20:51])
     assert np.array_equal(part_d.view(np.uint32), full_d[20:51].view(np.uint32))
+
+
+def oracle_bounce(oracle, sc):
+    """Per pixel: level-0 hit, hit point, reflected direction, occlusion words; level-1 hit and metric."""
+    H, W = sc.height, sc.width
+    words = max(1, (sc.desc.n_lights + 31) // 32)
+    hit0 = np.empty((H, W), dtype=np.int32)
+    point = np.zeros((H, W, 3)); refl = np.zeros((H, W, 3))
+    occl = np.zeros((H, W, words), dtype=np.uint32)
+    hit1 = np.full((H, W), -1, dtype=np.int32); d1 = np.zeros((H, W), dtype=np.float32)
+    for y in range(H):
+        o, v = oracle.camera_row(sc, y)
+        hit0[y], point[y], refl[y], occl[y] = oracle.bounce(sc, o, v)
+        h1, _, dist, _ = oracle.closest(sc, point[y], refl[y])
+        on = hit0[y] >= 0
+        hit1[y][on] = h1[on]; d1[y][on] = dist[on]
+    return hit0, point, refl, occl, hit1, d1
+
+
+@pytest.mark.parametrize("name,w,h", [("teapot", 96, 54), ("mixed_xf", 80, 60), ("campanile_teddy", 64, 36),
+                                     ("scene1", 64, 64), ("input-09", 48, 48), ("input-06", 64, 48),
+                                     ("synthetic_small", 80, 45), ("normals", 64, 48), ("input-11", 64, 48)])
+def test_shadow_bits_and_reflected_rays(name, w, h, oracle):
+    """Beyond the camera rays: the hit point and the reflected direction of every camera ray (bit for bit: they
+    feed the next level), which lights its shadow rays find blocked (Scene::traceShadowRay,
+    raytracer.cpp:551-558), and the nearest hit of the reflected ray (index and metric bits), against the
+    oracle's answers for the same rays, in every configuration of the trace kernels."""
+    from raytracer_amd.render import Renderer
+    sc = Scene.load(scene_file(name), w, h, 1)
+    hit0, point, refl, occl, hit1, d1 = oracle_bounce(oracle, sc)
+    on = hit0 >= 0
+    for label, opts in CONFIGS:
+        r = Renderer(sc)
+        for key, value in opts.items():
+            r.set_option(getattr(abi, "RT_OPT_" + key), value)
+        g_point, g_refl, g_occl, g_hit1, g_d1 = r.bounce_probe(sc.desc.n_lights)
+        r.close()
+        assert np.array_equal(g_point[on].view(np.uint64), point[on].view(np.uint64)), label
+        assert np.array_equal(g_refl[on].view(np.uint64), refl[on].view(np.uint64)), label
+        assert not g_point[~on].any() and not g_occl[~on].any()
+        assert np.array_equal(g_occl[on], occl[on]), (label, int((g_occl[on] != occl[on]).sum()))
+        assert np.array_equal(g_hit1[on], hit1[on]), (label, int((g_hit1[on] != hit1[on]).sum()))
+        assert (g_hit1[~on] == -1).all()
+        both = on & (hit1 >= 0)
+        assert np.array_equal(g_d1[both].view(np.uint32), d1[both].view(np.uint32)), label
+
+
+def test_deeper_levels_colour_against_the_oracle(oracle):
+    """The colour a camera ray returns at depth 0, 1, 2 and 3 (Scene::traceRay's recursion, raytracer.cpp:539-544)
+    from whole frames, pixel by pixel against the oracle's per-ray trace: the quantised value (raytracer.cpp:174-178)
+    of the oracle's double colour must be the GPU's byte except where pow's last ulp sits on a quantisation step."""
+    from raytracer_amd.render import Renderer
+    for depth in (0, 1, 2, 3):
+        sc = Scene.load(scene_file("input-11"), 64, 48, depth)
+        r = Renderer(sc)
+        r.render_frame()
+        img = r.download()
+        r.close()
+        differing = 0
+        for y in range(sc.height):
+            o, v = oracle.camera_row(sc, y)
+            rgb = oracle.trace(sc, o, v, depth)
+            want = np.minimum(np.trunc(rgb * np.float32(255.0)), 255).astype(np.int64)
+            got = img[sc.height - 1 - y, :, :3].astype(np.int64)
+            differing += int((np.abs(want - got).max(axis=-1) > 0).sum())
+            assert np.abs(want - got).max() <= 1, (depth, y)
+        assert differing <= 2, (depth, differing)
+
+
+IN_PLANE_SCENE = """cam 0 0 5  -1 -1 3  1 -1 3  -1 1 3  1 1 3
+lta 0.5 0.5 0.5
+ltp 0 4 4  0.8 0.8 0.8
+mat 0.2 0.9 0.2  0.5 0.5 0.5  0 0 0  1  0 0 0
+tri 10 0 -20  12 0 -20  11 0 -22
+mat 0.9 0.2 0.2  0.5 0.5 0.5  0.3 0.3 0.3  8  0.2 0.2 0.2
+sph 0 0 0 0.6
+tri -3 -0.8 -3  3 -0.8 -3  0 -0.8 3
+"""
+
+
+def test_in_plane_origin_branch(oracle, tmp_path):
+    """Triangle::intersection returns r = 0 / b -- a "hit" at the ray's own origin -- when the origin lies exactly in
+    the triangle's plane (a == 0) and the ray grazes it (|b| < eps), wherever the triangle is (raytracer.cpp:319-321).
+    Here the eye lies in the plane y = 0 of a triangle far outside the view: the scanlines next to the horizon
+    take that branch for every pixel and show that triangle instead of the sphere in front of the camera.  The
+    brute-force scan reproduces the oracle's frame and nearest hits and counts the events; a box hierarchy cannot
+    find such a hit (the documented limit of RT_OPT_USE_BVH), so the LBVH frame differs in exactly those pixels."""
+    from raytracer_amd.render import Renderer
+    path = tmp_path / "in_plane.scene"
+    path.write_text(IN_PLANE_SCENE)
+    sc = Scene.load(str(path), 80, 80, 2)
+    want, _ = oracle.render(sc)
+    want_obj, want_d = oracle_hits(oracle, sc)
+    rows = [y for y in range(80) if (want_obj[y] == 0).any()]
+    # (the scanlines whose |dir.y| rounds below eps = 0.05f: two on either side of the horizon line y = 40, where
+    # b = 0 makes r = 0 / 0 a NaN that is no hit, raytracer.cpp:525)
+    assert rows == [38, 39, 41, 42] and (want_obj[rows] == 0).all() and (want_d[rows] == 0).all()
+    for label, opts in [c for c in CONFIGS if "USE_BVH" not in c[1]]:
+        r = Renderer(sc)
+        for key, value in opts.items():
+            r.set_option(getattr(abi, "RT_OPT_" + key), value)
+        obj, d = r.primary_hits()
+        r.render_frame()
+        img, st = r.download(), r.stats()
+        r.close()
+        assert np.array_equal(obj, want_obj), label
+        assert np.array_equal(d[want_obj >= 0].view(np.uint32), want_d[want_obj >= 0].view(np.uint32)), label
+        worst, ndiff, _ = __import__("tests.oracle_api", fromlist=["compare"]).compare(img, want)
+        assert worst <= 1 and ndiff <= 2, (label, worst, ndiff)
+        if label != "exact":
+            assert st["in_plane_origin_hits"] >= len(rows) * 80, label
+    r = Renderer(sc)
+    r.set_option(abi.RT_OPT_USE_BVH, 1)
+    obj, _ = r.primary_hits()
+    r.close()
+    differs = obj != want_obj
+    assert differs.any() and not differs[[y for y in range(80) if y not in rows]].any()
