@@ -178,6 +178,7 @@ struct rt_ctx {
     DevBuf<v16f> tri_filt;
     DevBuf<TriExact> tri_exact;
     DevBuf<SphereRec> spheres;
+    DevBuf<SphereFilt> sphere_filt;
     DevBuf<Group> groups;
     DevBuf<double> xforms;
     DevBuf<int32_t> xf_identity, obj_kind, obj_slot, obj_material, obj_transform, obj_interp;
@@ -1277,6 +1278,7 @@ static int upload_scene(rt_ctx** out, const rt_scene_desc* d) {
     // ---- triangles: reference-precision records and both forms of the filter record ----
     std::vector<HostTri>& tris = c->h_tris;
     std::vector<SphereRec> sph;
+    std::vector<SphereFilt> sph_filt;
     c->h_slot.assign(N, -1);
     std::vector<int> tri_objects;            // Scene::objects indices of the triangles, in order
     for (int i = 0; i < N; i++) {
@@ -1289,6 +1291,19 @@ static int upload_scene(rt_ctx** out, const rt_scene_desc* d) {
             s.obj = i; s.xf = d->obj_transform[i]; s.identity = xf_ident[s.xf];
             c->h_slot[i] = (int32_t)sph.size();
             sph.push_back(s);
+            SphereFilt f{};
+            const double* I = &xf[48 * (size_t)s.xf + 16];
+            for (int r = 0; r < 3; r++) {
+                double row = 0;
+                for (int q = 0; q < 4; q++) { f.m[4 * r + q] = (float)I[4 * r + q]; if (q < 3) row += std::fabs(I[4 * r + q]); }
+                f.norm = std::max(f.norm, (float)(row * (1 + 1e-6)));
+                f.tabs += (float)(std::fabs(I[4 * r + 3]) * (1 + 1e-6));
+            }
+            for (int q = 0; q < 3; q++) { f.c[q] = (float)g[q]; f.tabs += (float)(std::fabs(g[q]) * (1 + 1e-6)); }
+            f.r2 = (float)s.r2;
+            f.identity = s.identity;
+            // (a transform or sphere whose floats are not finite: the pre-test keeps every pair, NaNs compare false)
+            sph_filt.push_back(f);
         } else {
             tri_objects.push_back(i);
         }
@@ -1443,7 +1458,7 @@ static int upload_scene(rt_ctx** out, const rt_scene_desc* d) {
     } while (0)
     // the per-object arrays go to the device straight from the caller's buffers
     const size_t n_obj = (size_t)N;
-    UP(spheres, sph); UP(xforms, xf); UP(xf_identity, xf_ident);
+    UP(spheres, sph); UP(sphere_filt, sph_filt); UP(xforms, xf); UP(xf_identity, xf_ident);
     UP(obj_kind, d->obj_kind, n_obj); UP(obj_material, d->obj_material, n_obj);
     UP(obj_transform, d->obj_transform, n_obj); UP(obj_interp, d->obj_interp, n_obj);
     UP(obj_geom, d->obj_geom, 9 * n_obj); UP(obj_normals, d->obj_normals, 9 * n_obj);
@@ -1451,7 +1466,7 @@ static int upload_scene(rt_ctx** out, const rt_scene_desc* d) {
 #undef UP
 
     DevScene& s = c->hs;
-    s.spheres = c->spheres.p;
+    s.spheres = c->spheres.p; s.sphere_filt = c->sphere_filt.p;
     s.xforms = c->xforms.p; s.xf_identity = c->xf_identity.p; s.obj_kind = c->obj_kind.p;
     s.obj_material = c->obj_material.p; s.obj_transform = c->obj_transform.p; s.obj_interp = c->obj_interp.p;
     s.obj_geom = c->obj_geom.p; s.obj_normals = c->obj_normals.p; s.materials = c->materials.p; s.lights = c->lights.p;
@@ -1800,7 +1815,7 @@ void rt_free(rt_ctx* c) {
     (void)hipDeviceSynchronize();
     for (auto& s : c->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    c->d_scene.release(); c->tri_filt.release(); c->tri_exact.release(); c->spheres.release(); c->groups.release();
+    c->d_scene.release(); c->tri_filt.release(); c->tri_exact.release(); c->spheres.release(); c->sphere_filt.release(); c->groups.release();
     c->xforms.release(); c->xf_identity.release(); c->obj_kind.release(); c->obj_slot.release();
     c->obj_material.release(); c->obj_transform.release(); c->obj_interp.release(); c->obj_geom.release();
     c->obj_normals.release(); c->materials.release(); c->lights.release(); c->own_frame.release();

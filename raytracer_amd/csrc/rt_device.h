@@ -36,6 +36,18 @@ struct __attribute__((aligned(16))) SphereRec {
     int32_t obj, xf, identity, pad;
 };
 
+// FP32 form of a sphere for the conservative pre-test of k_brute (see sphere_may_hit): the inverse
+// transform's upper three rows, centre and squared radius as floats, and the magnitudes the error
+// bound of the test needs.
+struct __attribute__((aligned(16))) SphereFilt {
+    float m[12];       // rows 0..2 of M^-1 (row-major 3 x 4): object-space point = m * (p, 1), direction = m * (v, 0)
+    float c[3], r2;    // centre, radius^2
+    float norm;        // largest row sum of |m[i][0..2]| (how much the transform can magnify a coordinate's rounding)
+    float tabs;        // |m[0][3]| + |m[1][3]| + |m[2][3]| + |c|_1 (magnitudes that enter the object-space offset p - c)
+    int32_t identity;  // the transform is the identity (rays stay as they are)
+    int32_t pad;
+};
+
 // Thresholds of the FP32 candidate filter for one kind of query against one transform
 // group.  A pair (ray, triangle) may be dropped only when the reference-precision test is
 // certain to miss; the thresholds follow from the magnitudes the group's rays and vertices
@@ -72,6 +84,7 @@ struct DevScene {
     const v16f* tri_filt;        // [n_regular + 1]: one padding record at the end
     const TriExact* tri_exact;
     const SphereRec* spheres;
+    const SphereFilt* sphere_filt;   // [n_spheres], same order
     const Group* groups;
     const double* xforms;        // [n_transforms][48]: M, inverse, inverse-transpose (row-major)
     const int32_t* xf_identity;  // [n_transforms] 1 when M is bit-for-bit the identity
@@ -178,6 +191,50 @@ __device__ __forceinline__ float sph_intersect_exact(const SphereRec& S, d3 pos,
     d3 p2 = add3(pos, scl3(vec, (double)t2));
     float d1 = dist_f(pos, p1), d2 = dist_f(pos, p2);
     return d1 < d2 ? t1 : t2;
+}
+
+// Conservative FP32 pre-test of a ray against a sphere: false only when Sphere::intersection
+// (raytracer.cpp:393-414) is certain to return its miss value -- the discriminant is negative beyond the
+// rounding of this evaluation, or both roots lie below eps (the ray points away from the sphere, or
+// leaves it within eps: `t1 < eps && t2 < eps`, raytracer.cpp:402).  Everything else, NaNs included,
+// goes on to the reference-precision test.  (wp, wv): the world-space ray as floats; p1, v1: the sums of
+// the absolute values of their components; transformed: take the ray into the sphere's object space
+// first (nearest-hit queries; shadow rays meet the untransformed sphere, raytracer.cpp:553).
+__device__ __forceinline__ bool sphere_may_hit(const SphereFilt& F, const bool transformed, float wpx, float wpy, float wpz,
+                                               float wvx, float wvy, float wvz, float p1, float v1, float eps) {
+    const float EPS32 = 1.1920929e-7f;
+    float px = wpx, py = wpy, pz = wpz, vx = wvx, vy = wvy, vz = wvz;
+    float norm = 1.0f;
+    if (transformed) {
+        px = __builtin_fmaf(F.m[0], wpx, __builtin_fmaf(F.m[1], wpy, __builtin_fmaf(F.m[2], wpz, F.m[3])));
+        py = __builtin_fmaf(F.m[4], wpx, __builtin_fmaf(F.m[5], wpy, __builtin_fmaf(F.m[6], wpz, F.m[7])));
+        pz = __builtin_fmaf(F.m[8], wpx, __builtin_fmaf(F.m[9], wpy, __builtin_fmaf(F.m[10], wpz, F.m[11])));
+        vx = __builtin_fmaf(F.m[0], wvx, __builtin_fmaf(F.m[1], wvy, F.m[2] * wvz));
+        vy = __builtin_fmaf(F.m[4], wvx, __builtin_fmaf(F.m[5], wvy, F.m[6] * wvz));
+        vz = __builtin_fmaf(F.m[8], wvx, __builtin_fmaf(F.m[9], wvy, F.m[10] * wvz));
+        norm = F.norm;
+    }
+    // how far the FP32 offset p - c and direction can be from the reference's doubles, per component
+    // (inputs rounded to float, matrix entries rounded to float, four roundings per coordinate)
+    const float dp = 16.0f * EPS32 * (norm * p1 + F.tabs), dv = 16.0f * EPS32 * norm * v1;
+    const float cx = px - F.c[0], cy = py - F.c[1], cz = pz - F.c[2];
+    const float dpc = __builtin_fmaf(vx, cx, __builtin_fmaf(vy, cy, vz * cz));
+    const float dd = __builtin_fmaf(vx, vx, __builtin_fmaf(vy, vy, vz * vz));
+    const float pp = __builtin_fmaf(cx, cx, __builtin_fmaf(cy, cy, cz * cz));
+    const float disc = __builtin_fmaf(dpc, dpc, -dd * (pp - F.r2));
+    // bounds on |p - c| and |v| (1.75 > sqrt(3): the per-component bounds as a length)
+    const float L = sqrtf(pp) + 1.75f * dp, V = sqrtf(dd) + 1.75f * dv;
+    const float e_dpc = 1.75f * (V * dp + L * dv) + 8.0f * EPS32 * V * L;
+    const float e_dd = 2.0f * V * 1.75f * dv + 8.0f * EPS32 * V * V;
+    const float e_pp = 2.0f * L * 1.75f * dp + 8.0f * EPS32 * (L * L + F.r2);
+    const float E = 2.0f * ((2.0f * fabsf(dpc) + e_dpc) * e_dpc + e_dd * (pp + F.r2) + (dd + e_dd) * e_pp +
+                            8.0f * EPS32 * (dpc * dpc + dd * (pp + F.r2))) + 1e-30f;
+    const bool no_root = disc < -E;
+    // the larger root, from above: (-dpc + sqrt(disc)) / dd
+    const float top = -dpc + e_dpc + sqrtf(fmaxf(disc + E, 0.0f)) * (1.0f + 4.0f * EPS32);
+    const float dd_lo = dd - e_dd;
+    const bool behind = (eps > 0.0f) & ((top < 0.0f) | ((dd_lo > 0.0f) & (top < eps * (1.0f - 1e-3f) * dd_lo)));
+    return !(no_root | behind);
 }
 
 // The nearest-hit metric of Scene::traceRay (raytracer.cpp:522-524): distance

@@ -1636,7 +1636,13 @@ k_brute(const DevScene* __restrict__ sc, const TriExact* __restrict__ exact, Tra
         if (valid) load_world_ray<MODE>(A, sc, ray, n_hits, &wpos, &wvec, &source);
 
         if (part == 0 && valid) {
+            // an FP32 pre-test decides most (ray, sphere) pairs; the rest take the reference's arithmetic
+            const float fpx = (float)wpos.x, fpy = (float)wpos.y, fpz = (float)wpos.z;
+            const float fvx = (float)wvec.x, fvy = (float)wvec.y, fvz = (float)wvec.z;
+            const float p1 = fabsf(fpx) + fabsf(fpy) + fabsf(fpz), v1 = fabsf(fvx) + fabsf(fvy) + fabsf(fvz);
             for (int s = 0; s < NS; s++) {
+                const SphereFilt& F = sc->sphere_filt[s];
+                if (!A.scan_all && !sphere_may_hit(F, MODE == 0 && !F.identity, fpx, fpy, fpz, fvx, fvy, fvz, p1, v1, eps)) continue;
                 const SphereRec& S = sc->spheres[s];
                 const double* X = sc->xforms + 48 * (size_t)S.xf;
                 d3 pos = wpos, vec = wvec;

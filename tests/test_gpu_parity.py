@@ -80,7 +80,10 @@ def test_gpu_equals_reference_golden(gold):
 
 @pytest.mark.parametrize("name,w,h,depth", [("mixed_xf", 160, 120, 4), ("input-09", 100, 80, 6), ("s3", 120, 90, 6),
                                            ("normals", 120, 90, 3), ("teapot", 64, 36, 2),
-                                           ("campanile_teddy", 48, 27, 1)])
+                                           ("campanile_teddy", 48, 27, 1),
+                                           # spheres and ellipsoids: the FP32 pre-test of k_brute
+                                           ("ellipse", 192, 108, 6), ("input-06", 128, 96, 6), ("journal2", 128, 96, 6),
+                                           ("synthetic_small", 96, 54, 4), ("input-07", 96, 96, 6), ("input-08", 96, 96, 6)])
 def test_exact_only_mode_equals_filtered_mode(name, w, h, depth):
     """The FP32 filter may only drop pairs the reference-precision test would reject:
     switching it off must not change a single byte, nor any count."""
