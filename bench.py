@@ -70,6 +70,8 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL; gloo stages through host memory and exists to "
                          "rehearse the N-rank flow on a box with fewer GPUs than ranks)")
+    ap.add_argument("--no-config5", action="store_true",
+                    help="skip the roofline-stress leg (1,000,000 triangles + 64 spheres, 16 lights, depth 8)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="one stream: no overlap of a level's shadow launches with the next level's nearest-hit launches")
     return ap.parse_args()
@@ -105,6 +107,81 @@ def cpu_baseline(args, gpu_rays_fn):
     out = leg(4, min(16, os.cpu_count() or 1))
     one = leg(16, 1)
     out["single_thread"] = {"value": one["value"], "unit": one["unit"], "sample": one["sample"]}
+    return out
+
+
+def config5_leg(steps):
+    """The roofline-stress configuration: a tessellated height field of 1,000,000 triangles + 64 reflective
+    spheres (every 4th an ellipsoid), 16 lights, depth 8 (tools/make_synthetic.py writes it as .scene / .obj
+    text, no random numbers).  Two measurements on this GPU:
+      plain_scan  a 512 x 288 frame with RT_OPT_BOUNDING_TESTS = 0: every ray x triangle pair takes the FP32
+                  triangle test (the scene takes the filter's per-test margin form) -- the FP32 roofline
+                  fraction of the brute-force scan on a mesh 158 times the teapot's size;
+      lbvh_8k     the full 7680 x 4320 frame through the GPU-built LBVH (brute force at that size is 3 x 10^14 pairs)."""
+    import tempfile
+    from raytracer_amd import Scene, abi
+    from raytracer_amd.render import Renderer
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        t0 = time.perf_counter()
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synthetic.py"), tmp], check=True, stdout=subprocess.DEVNULL)
+        path = os.path.join(tmp, "synthetic.scene")
+        t1 = time.perf_counter()
+        sc = Scene.load(path, 512, 288, 8)
+        t2 = time.perf_counter()
+        r = Renderer(sc)
+        t3 = time.perf_counter()
+        out["host"] = {"generate_text_s": t1 - t0, "parse_s": t2 - t1, "upload_s": t3 - t2}
+        r.set_option(abi.RT_OPT_BOUNDING_TESTS, 0)
+        r.set_option(abi.RT_OPT_PROFILE, 1)
+        r.render_frame()
+        r.reset_stats()
+        tp = time.perf_counter()
+        r.render_frame()
+        st = r.stats()
+        wall = time.perf_counter() - tp
+        n_tri, n_sph = st["n_triangles"], st["n_spheres"]
+        tri_share = n_tri / (n_tri + n_sph)
+        ms = st["closest_ms"] + st["anyhit_ms"]
+        tests = (st["closest_tests"] + st["anyhit_tests"]) * tri_share
+        rays = st["rays_primary"] + st["rays_reflect"] + st["rays_shadow"]
+        out["plain_scan"] = {"frame": "512x288", "triangles": n_tri, "spheres": n_sph, "filter_form": st["filter_form"],
+                             "rays": rays, "ray_triangle_tests": tests, "filter_kernels_ms": ms, "frame_ms": wall * 1e3,
+                             "achieved_tflops": tests * FLOP_TRI / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                             "frac_of_peak": tests * FLOP_TRI / (ms * 1e-3) / PEAK_FP32_VALU if ms > 0 else 0.0,
+                             "reference_precision_kernels_ms": st["exact_ms"],
+                             "note": "42 FLOP per ray x triangle test; reference_precision_kernels_ms holds the listed pairs "
+                                     "and the spheres (FP32 pre-test, survivors in the reference's arithmetic)"}
+        # the same small frame with the default bounding tests, and through the LBVH
+        r.set_option(abi.RT_OPT_BOUNDING_TESTS, 1)
+        r.set_option(abi.RT_OPT_PROFILE, 0)
+        r.render_frame()
+        r.reset_stats()
+        tp = time.perf_counter()
+        r.render_frame()
+        r.stats()
+        out["bounded_scan"] = {"frame": "512x288", "frame_ms": (time.perf_counter() - tp) * 1e3}
+        r.close()
+        sc8 = Scene.load(path, 7680, 4320, 8)
+        r = Renderer(sc8)
+        tb = time.perf_counter()
+        r.set_option(abi.RT_OPT_USE_BVH, 1)
+        build_s = time.perf_counter() - tb
+        r.render_frame()
+        r.reset_stats()
+        tp = time.perf_counter()
+        for _ in range(steps):
+            r.render_frame()
+        sb = r.stats()
+        wall = (time.perf_counter() - tp) / steps
+        rays = (sb["rays_primary"] + sb["rays_reflect"] + sb["rays_shadow"]) / steps
+        out["lbvh_8k"] = {"frame": "7680x4320", "steps": steps, "ms_per_step": wall * 1e3, "rays_per_frame": rays,
+                          "Mrays_per_s": rays / wall / 1e6, "bvh_build_s": build_s,
+                          "box_tests_per_ray": sb["bvh_node_tests"] / steps / max(1, rays),
+                          "leaf_tests_per_ray": sb["bvh_leaf_tests"] / steps / max(1, rays),
+                          "exact_retests_per_ray": sb["exact_tests"] / steps / max(1, rays),
+                          "flagged_rays": sb["flagged_rays"]}
+        r.close()
     return out
 
 
@@ -404,6 +481,8 @@ def main():
         line["roofline"] = roof
         if lbvh is not None:
             line["lbvh"] = lbvh
+        if world == 1 and not args.no_config5 and not args.exact_only:
+            line["config5"] = config5_leg(max(1, min(3, args.steps)))
         if world == 1 and not args.no_cpu_baseline:
             def gpu_rays(w, h):
                 sc = Scene.load(args.scene, w, h, args.depth)

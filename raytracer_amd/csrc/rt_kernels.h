@@ -543,9 +543,17 @@ struct PlaneGuard {
     // directions (unit axis, cosine and sine of the half-angle); qgraze: largest |n . axis-direction| at which a
     // plane with unit normal n still holds a direction the reference calls grazing (raytracer.cpp:319).
     // on = 1: bounds hold; 0: no bound (everything is in reach); -1: the bundle has no ray
-    float qm[8][5], qa[8][5], qgraze[8];
+    // The eleven numbers of a bundle wait in LDS (qsh: [bundle][12] floats -- centre, the two radii, axis, cosine,
+    // sine, grazing bound) and are fetched into vector registers for the judging of a chunk: in scalar
+    // registers they would push the batch records of the scan loop out (spilled to lanes of a vector register
+    // right behind their load, which serialises the prefetch).
+    const __attribute__((address_space(3))) float* qsh;
     int qon[8];
 };
+
+// Square root for the bounding questions of the judging stage: the hardware's v_sqrt_f32 (1 ulp), without the
+// refinement steps of sqrtf -- every use sits next to a relative slack of 1e-5 or more.
+__device__ __forceinline__ float judge_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
 template <int MODE, int RPL, int AXIS, bool ROBUST, int SHARED, int PRE, bool WORK>
 __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* shared, const cv4f* cone,
@@ -633,17 +641,19 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
     // Can bundle sb (PRE 4) reach the sphere (centre, rho)?  The ray's LINE against the sphere widened by the
     // origins' distance from the bundle's axis line, and the ray's HALF-line (the reference accepts no hit
     // behind the origin, raytracer.cpp:325) against the sphere widened by the whole ball of origins.
+    struct BundleRegs { float m[5], a[5], graze; };
+    BundleRegs QB[PRE == 4 ? RPL : 1];
     auto bundle_reach = [&](const int sb, const float cx, const float cy, const float cz, const float rho) -> bool {
-        const float dx = cx - guard.qm[sb][0], dy = cy - guard.qm[sb][1], dz = cz - guard.qm[sb][2];
+        const float dx = cx - QB[sb].m[0], dy = cy - QB[sb].m[1], dz = cz - QB[sb].m[2];
         const float dist2 = dx * dx + dy * dy + dz * dz;
-        const float dist = sqrtf(dist2);
-        const float fwd = dx * guard.qa[sb][0] + dy * guard.qa[sb][1] + dz * guard.qa[sb][2];
-        const float cb = guard.qa[sb][3], sbn = guard.qa[sb][4];
-        const float R1 = (rho + guard.qm[sb][3]) * (1.0f + 1e-5f);
-        const float cs1 = sqrtf(fmaxf(dist2 - R1 * R1, 0.0f));
+        const float dist = judge_sqrt(dist2);
+        const float fwd = dx * QB[sb].a[0] + dy * QB[sb].a[1] + dz * QB[sb].a[2];
+        const float cb = QB[sb].a[3], sbn = QB[sb].a[4];
+        const float R1 = (rho + QB[sb].m[3]) * (1.0f + 1e-5f);
+        const float cs1 = judge_sqrt(fmaxf(dist2 - R1 * R1, 0.0f));
         const bool line_reach = !(R1 < 0.999f * dist) | !(fabsf(fwd) < cs1 * cb - R1 * sbn - 1e-5f * dist);
-        const float R2 = (rho + guard.qm[sb][4]) * (1.0f + 1e-5f);
-        const float cs2 = sqrtf(fmaxf(dist2 - R2 * R2, 0.0f));
+        const float R2 = (rho + QB[sb].m[4]) * (1.0f + 1e-5f);
+        const float cs2 = judge_sqrt(fmaxf(dist2 - R2 * R2, 0.0f));
         const bool half_reach = !(R2 < 0.999f * dist) | !(fwd < cs2 * cb - R2 * sbn - 1e-5f * dist);
         return line_reach & half_reach;
     };
@@ -653,7 +663,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
     auto cone_reach = [&](const float4 rec) -> bool {
         float along = rec.x * guard.bx + rec.y * guard.by + rec.z * guard.bz;
         if (PRE == 2) along = fabsf(along);
-        const float ct = rec.w, st = sqrtf(fmaxf(1.0f - ct * ct, 0.0f));
+        const float ct = rec.w, st = judge_sqrt(fmaxf(1.0f - ct * ct, 0.0f));
         const bool in_reach = (ct < -1.0f) | !(along < ct * guard.bcos - st * guard.bsin - 1e-5f);
         const float aside = fabsf(rec.x * guard.fx + rec.y * guard.fy + rec.z * guard.fz);
         const bool in_fan = (ct < -1.0f) | !(ct * guard.fcos - st * guard.fsin > 0.0f) |
@@ -663,7 +673,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
     // PRE 3: the task's disc of origins in the light's plane against the disc `rec` = (-2 cu, -2 cv, rho^2 - c.c)
     auto disc_reach = [&](const float4 rec) -> bool {
         const float cu = -0.5f * rec.x, cv = -0.5f * rec.y;
-        const float rho = sqrtf(fmaxf(rec.z + cu * cu + cv * cv, 0.0f));      // (radius^2 = k + c.c; inf stays inf)
+        const float rho = judge_sqrt(fmaxf(rec.z + cu * cu + cv * cv, 0.0f));      // (radius^2 = k + c.c; inf stays inf)
         const float du = cu - guard.bx, dv = cv - guard.by, sum = rho + guard.bcos;
         return !(du * du + dv * dv > sum * sum * (1.0f + 1e-5f));
     };
@@ -673,7 +683,8 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                            unsigned long long* out) {
         if (PRE == 4) {
             // rec = centre, rho^2 - |C|^2; pl = (n, d0)
-            const float rho = sqrtf(fmaxf(rec.w + rec.x * rec.x + rec.y * rec.y + rec.z * rec.z, 0.0f));
+            float rho = 0.0f;
+            if (reach_possible) rho = judge_sqrt(fmaxf(rec.w + rec.x * rec.x + rec.y * rec.y + rec.z * rec.z, 0.0f));
 #pragma unroll
             for (int q = 0; q < RPL / 2; q++) {
                 bool live = false;
@@ -683,11 +694,13 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                     if (guard.qon[sb] < 0) continue;                     // (wave-uniform: the bundle holds no ray)
                     if (guard.qon[sb] == 0) { live = true; continue; }
                     // in-plane origin: the plane passes through the ball of origins and holds a grazing direction of the cone
-                    const float off = fabsf(pl.x * guard.qm[sb][0] + pl.y * guard.qm[sb][1] + pl.z * guard.qm[sb][2] - pl.w);
-                    const float g = fabsf(pl.x * guard.qa[sb][0] + pl.y * guard.qa[sb][1] + pl.z * guard.qa[sb][2]);
-                    // smallest |n . v| over the cone (<= 0: some v lies in the plane)
-                    const float steep = g * guard.qa[sb][3] - sqrtf(fmaxf(1.0f - g * g, 0.0f)) * guard.qa[sb][4];
-                    const bool is_named = !(off > guard.qm[sb][4] + 2.0f * guard.slack) & !(steep > guard.qgraze[sb]);
+                    const float off = fabsf(pl.x * QB[sb].m[0] + pl.y * QB[sb].m[1] + pl.z * QB[sb].m[2] - pl.w);
+                    const float g = fabsf(pl.x * QB[sb].a[0] + pl.y * QB[sb].a[1] + pl.z * QB[sb].a[2]);
+                    // the smallest |n . v| over the cone is g cos - sqrt(1 - g^2) sin (<= 0: some v lies in the plane);
+                    // "at most the grazing bound" without the root: lhs = g cos - bound <= sqrt(1 - g^2) sin
+                    const float lhs = g * QB[sb].a[3] - QB[sb].graze;
+                    const bool grazing = !(lhs > 0.0f) | !(lhs * lhs > (1.0f - g * g) * QB[sb].a[4] * QB[sb].a[4] * (1.0f + 1e-5f));
+                    const bool is_named = !(off > QB[sb].m[4] + 2.0f * guard.slack) & grazing;
                     live |= is_named;
                     if (reach_possible) live |= bundle_reach(sb, rec.x, rec.y, rec.z, rho);
                 }
@@ -733,6 +746,15 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
         if (PRE) {
             live_groups = 0ull;
             const int n_grp = (cend - cbeg + 63) >> 6;
+            if (PRE == 4) {
+                const volatile __attribute__((address_space(3))) float* q = guard.qsh;   // (volatile: fetched here, for this chunk's judging only)
+#pragma unroll
+                for (int sb = 0; sb < RPL; sb++) {
+#pragma unroll
+                    for (int k = 0; k < 5; k++) { QB[sb].m[k] = q[12 * sb + k]; QB[sb].a[k] = q[12 * sb + 5 + k]; }
+                    QB[sb].graze = q[12 * sb + 10];
+                }
+            }
             // clusters first, one per lane (a chunk holds at most 64 and starts at a multiple of 64) ...
             const unsigned long long cl_reach = __ballot(lane < n_grp && cluster_reach((cbeg >> 6) + lane));
             if (WORK) wk.v[RT_WK_CLUSTERS] += (unsigned int)n_grp;
@@ -1066,11 +1088,13 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
     // constant address space lets the compiler use scalar loads (s_load_dwordx16).
     const cv16f* filt = (const cv16f*)filt_global;
     __shared__ unsigned short cand[RT_CAND_CAP * RT_BLOCK];
+    __shared__ float bundle_all[(CONE == 4) ? (RT_BLOCK / RT_WAVE) * 8 * 12 : 1];
     const int lane = threadIdx.x & (RT_WAVE - 1);
     // threadIdx.x / 64 is the same in every lane of a wave; say so, so that everything
     // derived from it (task, triangle index) stays in scalar registers.
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / RT_WAVE);
     unsigned short* my_cand = cand + wave_in_block * RT_WAVE + lane;   // entry k at my_cand[k * RT_BLOCK]
+    float* bundle_sh = bundle_all + ((CONE == 4) ? wave_in_block * 8 * 12 : 0);   // this wave's bundles (see PlaneGuard::qsh)
     const unsigned int n_waves = gridDim.x * (RT_BLOCK / RT_WAVE);
     constexpr unsigned int RAYS_PER_TASK = RT_WAVE * RPL;
 
@@ -1270,7 +1294,7 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                 }
             }
             PlaneGuard guard = {};
-            if (CONE == 4) { guard.planes = A.plane_any; guard.cl_bounds = A.cl_sphere; guard.cl_normals = A.cl_normal; }
+            if (CONE == 4) { guard.planes = A.plane_any; guard.cl_bounds = A.cl_sphere; guard.cl_normals = A.cl_normal; guard.qsh = (const __attribute__((address_space(3))) float*)bundle_sh; }
             if (CONE == 1) guard.cl_bounds = A.cl_camera;
             if (CONE == 2) {
                 guard.cl_bounds = A.cl_lights + (size_t)light * (size_t)(A.n_clusters + 1) * 4;
@@ -1394,12 +1418,13 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                         const float racross = sqrtf(fmaxf(across2, 0.0f) + 8e-7f * far2) * (1.0f + 1e-5f) + along1 * sn * (1.0f + 1e-5f) + pad;
                         // (a NaN anywhere makes the axis NaN: fminf would drop it, the flags do not)
                         const bool finite = (ax == ax) && (ay == ay) && (az == az) && (rfull == rfull) && (racross == racross) && (low == low);
-                        guard.qa[sb][0] = uniform_f(ax); guard.qa[sb][1] = uniform_f(ay); guard.qa[sb][2] = uniform_f(az);
-                        guard.qa[sb][3] = uniform_f(cb); guard.qa[sb][4] = uniform_f(sn);
-                        guard.qm[sb][0] = uniform_f(mx); guard.qm[sb][1] = uniform_f(my); guard.qm[sb][2] = uniform_f(mz);
-                        guard.qm[sb][3] = uniform_f(fminf(racross, rfull)); guard.qm[sb][4] = uniform_f(rfull);
+                        if (lane == 0) {
+                            float* q = bundle_sh + 12 * sb;
+                            q[0] = mx; q[1] = my; q[2] = mz; q[3] = fminf(racross, rfull); q[4] = rfull;
+                            q[5] = ax; q[6] = ay; q[7] = az; q[8] = cb; q[9] = sn;
+                        }
                         // |n . V| <= b_hi with V = |V| v: |n . v| <= b_hi / |V| <= b_hi * sqrt(largest 1 / |V|^2)
-                        guard.qgraze[sb] = uniform_f(fp.b_hi * sqrtf(slow) * (1.0f + 1e-4f) + 4e-6f);
+                        if (lane == 0) bundle_sh[12 * sb + 10] = fp.b_hi * sqrtf(slow) * (1.0f + 1e-4f) + 4e-6f;
                         guard.qon[sb] = __builtin_amdgcn_readfirstlane(!(cnt > 0.5f) ? -1 : ((finite && cb > 0.0f) ? 1 : 0));
 #ifdef RT_X_HIST
                         if (WORK && lane == 0 && A.work && part == 0 && cnt > 0.5f) {

@@ -135,7 +135,7 @@ def test_two_rank_benchmark_flow_on_one_gpu():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    common = ["--steps", "1", "--warmup", "0", "--width", "640", "--height", "360", "--no-cpu-baseline", "--no-lbvh"]
+    common = ["--steps", "1", "--warmup", "0", "--width", "640", "--height", "360", "--no-cpu-baseline", "--no-lbvh", "--no-config5"]
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common,
                          check=True, capture_output=True, text=True, timeout=300).stdout
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
