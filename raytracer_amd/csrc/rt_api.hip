@@ -420,6 +420,7 @@ int launch_trace(rt_ctx* c, const Workspace& W, TraceArgs A, hipStream_t st, siz
     A.cl_sphere = c->cl_sphere.p; A.cl_normal = c->cl_normal.p; A.n_clusters = c->n_clusters;
     A.pair_count = (unsigned long long*)W.ray_flags[MODE];
     A.task_counter = (unsigned int*)(A.pair_count + 1);
+    A.any_flagged = A.task_counter + 1;           // (the 16-byte header: pair count, task counter, "some ray is flagged")
     A.ray_flags = W.ray_flags[MODE] + 16; A.pairs = W.pairs[MODE];
     A.pair_cap = (unsigned int)W.pair_cap[MODE]; A.counters = c->counters.p; A.scan_all = c->force_exact;
     const bool work = c->work_counters && c->work.p;

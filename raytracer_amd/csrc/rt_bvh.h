@@ -330,8 +330,11 @@ k_bvh_trace(const DevScene* __restrict__ sc, BvhArgs B, TraceArgs A) {
                 const BvhNode& N = nodes[cur];
                 n_node += 2;
                 float tn0, tn1;
-                const bool h0 = N.child[0] != RT_BVH_NO_CHILD && ray_reaches_box(N.lo[0], N.hi[0], px, py, pz, ix, iy, iz, &tn0) && !(tn0 > t_limit);
-                const bool h1 = N.child[1] != RT_BVH_NO_CHILD && ray_reaches_box(N.lo[1], N.hi[1], px, py, pz, ix, iy, iz, &tn1) && !(tn1 > t_limit);
+                // (no short-circuit: both boxes are tested whatever the answers, without a branch between them)
+                const bool r0 = ray_reaches_box(N.lo[0], N.hi[0], px, py, pz, ix, iy, iz, &tn0);
+                const bool r1 = ray_reaches_box(N.lo[1], N.hi[1], px, py, pz, ix, iy, iz, &tn1);
+                const bool h0 = r0 & !(tn0 > t_limit) & (N.child[0] != RT_BVH_NO_CHILD);
+                const bool h1 = r1 & !(tn1 > t_limit) & (N.child[1] != RT_BVH_NO_CHILD);
                 if (h0 && h1) {
                     const int near = tn1 < tn0 ? 1 : 0;
                     if (sp == RT_BVH_STACK + RT_BVH_SPILL) { bail = true; active = false; break; }
@@ -371,7 +374,7 @@ k_bvh_trace(const DevScene* __restrict__ sc, BvhArgs B, TraceArgs A) {
                 }
             }
         }
-        if (valid && bail) A.ray_flags[ray] = 1;
+        if (valid && bail) { A.ray_flags[ray] = 1; *A.any_flagged = 1u; }
         if (MODE == 0 && valid && best != RT_MISS_KEY) atomicMin(&A.keys[ray], best);
     }
     for (int off = 32; off > 0; off >>= 1) {

@@ -154,6 +154,8 @@ struct TraceArgs {
     unsigned long long* pairs;           // (ray << 32) | exact-record slot
     unsigned long long* pair_count;      // pairs appended so far (may run past pair_cap: the surplus is dropped)
     unsigned int* task_counter;          // k_filter: next task to hand out (zeroed before the launch)
+    unsigned int* any_flagged;           // set to 1 by whoever sets a ray flag (zeroed before the launch): lets k_brute
+                                         // leave at once when no ray is flagged and the scene has nothing else for it
     unsigned int pair_cap;
     DevCounters* counters;
     // Per regular-triangle constants that let k_filter skip work shared by all rays of a launch:
@@ -442,7 +444,7 @@ __device__ __forceinline__ int flush_candidates(const TraceArgs& A, const unsign
 #pragma unroll
         for (int r = 0; r < RPL; r++) {
             const unsigned int ray = ray0 + r * RT_WAVE;
-            if (ray < n_rays && n_cand > 0) A.ray_flags[ray] = 1;
+            if (ray < n_rays && n_cand > 0) { A.ray_flags[ray] = 1; *A.any_flagged = 1u; }
         }
     }
     unsigned long long at = base;
@@ -740,9 +742,6 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
     for (cbeg = abeg; cbeg < aend; cbeg += CHUNK) {
         const int cend = min(cbeg + CHUNK, aend);
         n_cand = 0;
-#ifdef RT_X_CYCLES
-        const unsigned long long t_judge0 = __builtin_readcyclecounter();
-#endif
         if (PRE) {
             live_groups = 0ull;
             const int n_grp = (cend - cbeg + 63) >> 6;
@@ -783,9 +782,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                         group_masks(cbeg + gi[u] * 64 + lane, cend, rec[u], pl[u], reach_possible, out);
                         if (WORK) {
                             wk.v[RT_WK_GROUPS]++;
-#ifndef RT_X_CYCLES
                             if (reach_possible) wk.v[RT_WK_GROUP_TESTS] += (unsigned int)min(64, cend - (cbeg + gi[u] * 64)) * (PRE == 4 ? RPL : 1);
-#endif
                         }
                         unsigned long long any = out[0];
                         if (PRE == 4) {
@@ -840,10 +837,6 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                 }
             }
         }
-#ifdef RT_X_CYCLES
-        const unsigned long long t_judge1 = __builtin_readcyclecounter();
-        if (WORK) wk.v[RT_WK_GROUP_TESTS] += (unsigned int)((t_judge1 - t_judge0) >> 4);
-#endif
         for (int j0 = cbeg; j0 < cend; j0 += RT_BATCH) {
             int jn = min(j0 + RT_BATCH, cend);
             int j_next = j0 + RT_BATCH;               // where the scan goes on after this batch
@@ -926,9 +919,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                 if (PRE == 2 || PRE == 3) named = (unsigned int)(guard_mask >> (j0 - guard_base)) & ((1u << RT_BATCH) - 1u);
                 if (WORK) {
                     wk.v[RT_WK_BATCHES]++;
-#ifndef RT_X_CYCLES
                     if (PRE != 4) wk.v[RT_WK_RAY_BOUND_TESTS] += RT_WAVE * RPL * RT_BATCH;
-#endif
                 }
 #pragma unroll
                 for (int jb = 0; jb < RT_BATCH; jb++) {
@@ -981,9 +972,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
 #pragma unroll
                     for (int q = 0; q < RPL / 2; q++) {
                         if (((pair_mask[q] >> (j0 - guard_base)) & ((1ull << RT_BATCH) - 1ull)) == 0ull) continue;
-#ifndef RT_X_CYCLES
                         if (WORK) wk.v[RT_WK_RAY_BOUND_TESTS] += RT_WAVE * 2 * RT_BATCH;
-#endif
                         v2f t[RT_BATCH], d[RT_BATCH], a[RT_BATCH];
 #pragma unroll
                         for (int jb = 0; jb < RT_BATCH; jb++) {
@@ -1071,9 +1060,6 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
             }
             j0 = j_next - RT_BATCH;
         }
-#ifdef RT_X_CYCLES
-        if (WORK) wk.v[RT_WK_RAY_BOUND_TESTS] += (unsigned int)((__builtin_readcyclecounter() - t_judge1) >> 4);
-#endif
     }
 }
 
@@ -1120,7 +1106,16 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
 #ifndef RT_TASKS_PER_WAVE_BOUNDED
 #define RT_TASKS_PER_WAVE_BOUNDED 3
 #endif
-    const unsigned int per_wave = CONE ? RT_TASKS_PER_WAVE_BOUNDED : 8u;       // tasks per wave to aim for
+#ifndef RT_TASKS_PER_WAVE_SHADOW
+#define RT_TASKS_PER_WAVE_SHADOW 6
+#endif
+#ifndef RT_TASKS_PER_WAVE_ANY
+#define RT_TASKS_PER_WAVE_ANY 6
+#endif
+    // tasks per wave to aim for (camera rays cost alike and want few, long tasks; the tasks of shadow and
+    // reflection rays differ a lot in cost, and the launch ends with its longest one)
+    const unsigned int per_wave = CONE == 1 ? RT_TASKS_PER_WAVE_BOUNDED : CONE == 2 ? RT_TASKS_PER_WAVE_SHADOW
+                                : CONE == 4 ? RT_TASKS_PER_WAVE_ANY : 8u;
     if (n_ray_blocks < per_wave * n_waves) {
         split = (int)((per_wave * n_waves + n_ray_blocks - 1) / n_ray_blocks);
         if (split > max_split) split = max_split;
@@ -1152,10 +1147,6 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
         if (task >= n_tasks) break;
         WorkCount wk = {};
         if (WORK) wk.v[RT_WK_TASKS] = 1;
-#ifdef RT_X_CYCLES
-        const unsigned long long t_task0 = __builtin_readcyclecounter();
-        unsigned long long t_setup = 0;
-#endif
         // integer division goes through the vector ALU; its result is still wave-uniform
         const int part = __builtin_amdgcn_readfirstlane((int)(task / n_ray_blocks));
         const unsigned int rb = task - (unsigned int)part * n_ray_blocks;
@@ -1260,7 +1251,7 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                         box_hi[0] = fmaxf(box_hi[0], fx); box_hi[1] = fmaxf(box_hi[1], fy); box_hi[2] = fmaxf(box_hi[2], fz);
                     }
                     if (!trusted) {
-                        if (valid && part == 0) A.ray_flags[ray] = 1;
+                        if (valid && part == 0) { A.ray_flags[ray] = 1; *A.any_flagged = 1u; }
                         // (camera rays keep the origin they all share)
                         if (CONE != 1) { fx = 0.f; fy = 0.f; fz = 0.f; }
                         gx = 0.f; gy = 0.f; gz = 1.f;
@@ -1426,15 +1417,6 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                         // |n . V| <= b_hi with V = |V| v: |n . v| <= b_hi / |V| <= b_hi * sqrt(largest 1 / |V|^2)
                         if (lane == 0) bundle_sh[12 * sb + 10] = fp.b_hi * sqrtf(slow) * (1.0f + 1e-4f) + 4e-6f;
                         guard.qon[sb] = __builtin_amdgcn_readfirstlane(!(cnt > 0.5f) ? -1 : ((finite && cb > 0.0f) ? 1 : 0));
-#ifdef RT_X_HIST
-                        if (WORK && lane == 0 && A.work && part == 0 && cnt > 0.5f) {
-                            const float cbu = uniform_f(cb), rou = uniform_f(fminf(racross, rfull));
-                            int bin = cbu > 0.99985f ? 0 : cbu > 0.99939f ? 1 : cbu > 0.9962f ? 2 : cbu > 0.9848f ? 3 : cbu > 0.9397f ? 4 : cbu > 0.7071f ? 5 : 6;
-                            atomicAdd(&A.work[bin], 1ull);
-                            int rbin = rou < 0.01f ? 7 : rou < 0.05f ? 8 : 9;
-                            atomicAdd(&A.work[rbin], 1ull);
-                        }
-#endif
                     }
                 }
             }
@@ -1510,9 +1492,6 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
 #pragma unroll
                 for (int k = 0; k < RPL / 2; k++) { L.px[k] = {ex, ex}; L.py[k] = {ey, ey}; L.pz[k] = {ez, ez}; }
             }
-#ifdef RT_X_CYCLES
-            t_setup = __builtin_readcyclecounter() - t_task0;
-#endif
             // each part takes its share of every axis range
 #pragma unroll
             for (int axis = 0; axis < 3; axis++) {
@@ -1563,12 +1542,6 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
 #undef RT_RANGE
             }
         }
-#ifdef RT_X_CYCLES
-        if (WORK) {
-            wk.v[RT_WK_TRI_WANTED] = (unsigned int)(t_setup >> 4);
-            wk.v[RT_WK_TRI_TESTS] = (unsigned int)((__builtin_readcyclecounter() - t_task0) >> 4);
-        }
-#endif
         if (WORK && lane == 0 && A.work) {
             const int kind = (CONE == 1) ? 1 : (CONE == 4) ? 4 : (CONE == 2) ? cone_kind : (MODE == 0 ? 0 : 5);
 #pragma unroll
@@ -1632,6 +1605,8 @@ k_brute(const DevScene* __restrict__ sc, const TriExact* __restrict__ exact, Tra
     const unsigned int n_ray_blocks = (n_rays + RT_WAVE - 1) / RT_WAVE;
     if (n_ray_blocks == 0) return;
     const int NR = sc->n_regular, NI = sc->n_irregular, NS = sc->n_spheres;
+    // nothing but flagged rays could need this kernel, and no ray is flagged: done (one scalar load)
+    if (NS + NI == 0 && !A.scan_all && __builtin_amdgcn_readfirstlane(*(const volatile unsigned int*)A.any_flagged) == 0u) return;
     int max_split = (NR + 255) / 256;
     if (max_split < 1) max_split = 1;
     int split = 1;
