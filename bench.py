@@ -185,30 +185,29 @@ def config5_leg(steps):
     return out
 
 
-def measured_traffic(kernel_label, launches_per_frame):
-    """HBM bytes per launch of the dominant kernel from the committed PMC pass of this same
-    command (profiles/*pmc_summary.csv, written by tools/pmc_passes.sh + tools/pmc_summary.py):
+def measured_traffic(mode, bounding_test):
+    """HBM bytes per launch of one scan kernel from the committed PMC passes of this same command
+    (profiles/*pmc_summary.csv, written by tools/pmc_passes.sh + tools/pmc_summary.py):
     FETCH_SIZE is in KiB and reads half the bytes of a wide stream on gfx950 (doubled here),
-    WRITE_SIZE is in KiB and exact.  None when no such file exists."""
+    WRITE_SIZE is in KiB and exact; both are sums over the DISPATCHES launches of one pass.
+    The kernel is k_filter<MODE, rays per lane, form, bounding test, counting> with counting = false.
+    None when no such file or kernel exists."""
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.csv")))
     if not files:
         return None
-    fetch = write = None
+    got = {}
     for r in csv.DictReader(open(files[-1])):
         name = r["kernel"].replace(" ", "")
-        # (k_filter<MODE, rays per lane, form, bounding test>: the scan without a bounding test ends in 0>)
-        if name.startswith("k_filter<0," if "<0," in kernel_label else "k_filter<1,") and name.endswith(",0>"):
-            if r["counter"] == "FETCH_SIZE":
-                fetch = float(r["sum_over_dispatches"])
-            if r["counter"] == "WRITE_SIZE":
-                write = float(r["sum_over_dispatches"])
-    if fetch is None or write is None or launches_per_frame <= 0:
+        if not (name.startswith("k_filter<") and name.endswith(">")):
+            continue
+        targs = name[len("k_filter<"):-1].split(",")
+        if len(targs) == 5 and targs[0] == str(mode) and targs[3] == str(bounding_test) and targs[4] == "false":
+            got[r["counter"]] = float(r["sum_over_dispatches"])
+    if not all(k in got for k in ("FETCH_SIZE", "WRITE_SIZE", "DISPATCHES")) or got["DISPATCHES"] <= 0:
         return None
-    # the PMC passes run `bench.py --steps 1 --warmup 0 --no-lbvh`: the plain scan runs in two frames there
-    # (the warm-up frame and the timed frame of the RT_OPT_BOUNDING_TESTS = 0 leg)
-    return (2.0 * fetch + write) * 1024.0 / (2.0 * launches_per_frame)
+    return (2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024.0 / got["DISPATCHES"]
 
 
 def main():
@@ -336,7 +335,7 @@ def main():
                 "box_tests_per_ray": sb["bvh_node_tests"] / max(1, lb_rays),
                 "leaf_tests_per_ray": sb["bvh_leaf_tests"] / max(1, lb_rays),
                 "exact_retests_per_ray": sb["exact_tests"] / max(1, lb_rays),
-                "note": "frames byte-identical to brute force (tests/test_gpu_bvh.py)"}
+                "note": "frames byte-identical to brute force on the bundled scenes (tests/test_gpu_bvh.py); a ray that starts exactly in the plane of a triangle whose box it does not reach is the one documented exception (RT_OPT_USE_BVH in include/rt_abi.h)"}
 
     rays_local = st_timed["rays_primary"] + st_timed["rays_reflect"] + st_timed["rays_shadow"]
     if world > 1:
@@ -449,7 +448,7 @@ def main():
                          "priced at the algorithmic 42 FLOP per test; NOT the timed configuration (it takes %.1f ms per frame)"
                          % (both_ms / args.steps),
                  # (the committed PMC pass is a 1-GPU run: its per-launch bytes describe N = 1 only)
-                 "traffic": measured_traffic(dom, launches / max(1, args.steps)) if world == 1 and launches else None,
+                 "traffic": measured_traffic(0 if "<0," in dom else 1, 0) if world == 1 and launches else None,
                  "traffic_source": "replayed from the committed PMC summary under profiles/ (not measured in this run)",
                  "kernel_ms_avg": ms / max(1, launches), "launches": launches,
                  "flop_per_test": flop_per_test, "tests_per_launch": tests / max(1, launches),
@@ -470,11 +469,16 @@ def main():
             names = {"camera_rays": "k_filter<0, %d, form, 1> (camera rays)" % 8,
                      "reflection_rays": "k_filter<0, %d, form, 4> (reflection rays)" % 4,
                      "shadow_rays": "k_filter<1, %d, form, 2> (shadow rays)" % 8}
+            pmc_key = {"camera_rays": (0, 1), "reflection_rays": (0, 4), "shadow_rays": (1, 2)}
             dom_scan = max(names, key=lambda k: executed[k]["ms_per_step"])
             roof.update({"kernel": names[dom_scan] + ": the scan kernel of the timed configuration with the largest share of "
                                                       "the frame; executed FP32 operations of its three stages (bundle judgement, "
                                                       "per-ray bounding test, triangle test) over its duration",
                          "achieved": executed[dom_scan]["executed_tflops"], "frac": executed[dom_scan]["frac_of_peak"],
+                         # (the committed PMC pass is a 1-GPU run: its per-launch bytes describe N = 1 only)
+                         "traffic": measured_traffic(*pmc_key[dom_scan]) if world == 1 else None,
+                         "traffic_source": "HBM bytes per launch, replayed from the committed PMC summary under profiles/ "
+                                           "(not measured in this run)",
                          "timed_configuration": executed})
         else:
             roof.update({"kernel": plain["kernel"], "achieved": plain["achieved"], "frac": plain["frac"]})

@@ -3,7 +3,8 @@
 # (counters of one hardware block must fit that block's slots).
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/pmc_${TAG:-r1}
+OUT=gpurun_out/pmc_${TAG:-r2}
+rm -rf $OUT
 mkdir -p $OUT
 # two brute-force frames per pass: the timed one and the one of the kernel-timing leg
 CMD="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-lbvh --no-config5"
@@ -13,4 +14,5 @@ run sq2 SQ_INSTS_SMEM SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST
 run fetch FETCH_SIZE && \
 run write WRITE_SIZE && \
 run tcc TCC_HIT_sum TCC_MISS_sum && \
-run grbm GRBM_GUI_ACTIVE
+run grbm GRBM_GUI_ACTIVE && \
+run mix SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_CVT
