@@ -53,3 +53,11 @@ asan:
 	  -Lasan_build -lrt_host -lraytracer_amd -L/opt/rocm/lib -lamdhip64 -lrccl -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 
 .PHONY: all host hip cli oracle clean microbench asan
+
+# A build of the device library with extra flags under variants/ (A/B measurements, diagnostic builds):
+#   make variant NAME=phase FLAGS=-DRT_PHASE_CLOCK  ->  variants/libraytracer_amd_phase.so  (RAYTRACER_AMD_LIB selects it)
+variant:
+	mkdir -p variants
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -Iinclude -I$(PKG)/csrc \
+	  $(FLAGS) -o variants/libraytracer_amd_$(NAME).so $(HIP_SRC)
+.PHONY: variant

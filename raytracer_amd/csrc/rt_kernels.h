@@ -208,7 +208,20 @@ enum {
     RT_WK_LISTED,           // pairs listed for the reference-precision re-test
     RT_WK_CLUSTERS          // clusters of 64 triangles judged (one lane each, one level above the groups)
 };
-struct WorkCount { unsigned int v[RT_WORK_FIELDS]; };
+struct WorkCount {
+    unsigned int v[RT_WORK_FIELDS];
+#ifdef RT_PHASE_CLOCK
+    unsigned int t[8];      // shader cycles by phase of a task (see k_filter)
+#endif
+};
+// Diagnostic build (-DRT_PHASE_CLOCK): the counting instances of the scan kernels report, in place of the
+// executed-work counts, the shader cycles (s_memtime) a wave spends in each phase of its tasks, summed over
+// waves: field 1 waiting for the task number, 2 loading the task's rays and building their bundles, 3 judging
+// clusters and groups, 4 the batch loop (per-ray bounding tests, triangle tests) without 5 the flushes of the
+// staged candidates, 6 whole tasks, 7 the waves' lifetimes; field 0 stays the number of tasks.
+#ifdef RT_PHASE_CLOCK
+#define RT_CLOCK() ((unsigned int)__builtin_readcyclecounter())
+#endif
 
 // Shadow rays are numbered light-major: ray = light * n_hits + hit, so that rays towards one
 // light are neighbours (a block of rays towards a directional light shares its direction).
@@ -742,6 +755,10 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
     for (cbeg = abeg; cbeg < aend; cbeg += CHUNK) {
         const int cend = min(cbeg + CHUNK, aend);
         n_cand = 0;
+#ifdef RT_PHASE_CLOCK
+        const unsigned int clk_judge = RT_CLOCK();
+        unsigned int clk_flush = 0;
+#endif
         if (PRE) {
             live_groups = 0ull;
             const int n_grp = (cend - cbeg + 63) >> 6;
@@ -837,6 +854,10 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                 }
             }
         }
+#ifdef RT_PHASE_CLOCK
+        const unsigned int clk_scan = RT_CLOCK();
+        if (WORK) wk.t[2] += clk_scan - clk_judge;
+#endif
         for (int j0 = cbeg; j0 < cend; j0 += RT_BATCH) {
             int jn = min(j0 + RT_BATCH, cend);
             int j_next = j0 + RT_BATCH;               // where the scan goes on after this batch
@@ -1054,12 +1075,21 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
             // and at the end of the chunk (entries are relative to the chunk base).
             const bool last = j_next >= cend;
             if (__any(n_cand > RT_CAND_CAP - RT_BATCH * RPL) || (last && __any(n_cand > 0))) {
+#ifdef RT_PHASE_CLOCK
+                const unsigned int clk_f0 = RT_CLOCK();
+#endif
                 const int listed = flush_candidates<RPL>(A, my_cand, n_cand, cbeg, ray0, n_rays, lane);
                 if (WORK) wk.v[RT_WK_LISTED] += (unsigned int)listed;
                 n_cand = 0;
+#ifdef RT_PHASE_CLOCK
+                clk_flush += RT_CLOCK() - clk_f0;
+#endif
             }
             j0 = j_next - RT_BATCH;
         }
+#ifdef RT_PHASE_CLOCK
+        if (WORK) { wk.t[3] += RT_CLOCK() - clk_scan - clk_flush; wk.t[4] += clk_flush; }
+#endif
     }
 }
 
@@ -1136,9 +1166,18 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
     // floor of ~0.1 ms under every launch.
     const unsigned int wave_id = blockIdx.x * (RT_BLOCK / RT_WAVE) + (unsigned int)wave_in_block;
     bool first_task = true;
+#ifdef RT_PHASE_CLOCK
+    const unsigned int clk_wave = RT_CLOCK();
+    unsigned long long clk_sum[7] = {0, 0, 0, 0, 0, 0, 0};      // tasks, then the six phases: flushed once per wave
+#endif
     for (;;) {
+#ifdef RT_PHASE_CLOCK
+        const unsigned int clk_t0 = RT_CLOCK();
+#endif
         unsigned int task = wave_id;
         if (!first_task) {
+            // (asked for here, not ahead of time: a ticket requested a task early returns in front of the task's ray
+            // loads in the wave's memory queue and was measured slower, 3.45 -> 3.62 ms on the reflection scan)
             unsigned int t = 0;
             if (lane == 0) t = atomicAdd(A.task_counter, 1u);
             task = n_waves + (unsigned int)__builtin_amdgcn_readfirstlane(t);
@@ -1147,6 +1186,10 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
         if (task >= n_tasks) break;
         WorkCount wk = {};
         if (WORK) wk.v[RT_WK_TASKS] = 1;
+#ifdef RT_PHASE_CLOCK
+        const unsigned int clk_t1 = RT_CLOCK();
+        wk.t[0] = clk_t1 - clk_t0;
+#endif
         // integer division goes through the vector ALU; its result is still wave-uniform
         const int part = __builtin_amdgcn_readfirstlane((int)(task / n_ray_blocks));
         const unsigned int rb = task - (unsigned int)part * n_ray_blocks;
@@ -1492,6 +1535,9 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
 #pragma unroll
                 for (int k = 0; k < RPL / 2; k++) { L.px[k] = {ex, ex}; L.py[k] = {ey, ey}; L.pz[k] = {ez, ez}; }
             }
+#ifdef RT_PHASE_CLOCK
+            if (g == 0) wk.t[1] = RT_CLOCK() - clk_t1;
+#endif
             // each part takes its share of every axis range
 #pragma unroll
             for (int axis = 0; axis < 3; axis++) {
@@ -1542,6 +1588,19 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
 #undef RT_RANGE
             }
         }
+#ifdef RT_PHASE_CLOCK
+        wk.t[5] = RT_CLOCK() - clk_t0;
+        clk_sum[0] += 1;
+        for (int f = 0; f < 6; f++) clk_sum[1 + f] += wk.t[f];
+        if (WORK && lane == 0 && A.work && (CONE == 4 || CONE == 2)) {
+            // histogram of task durations: bucket b holds tasks of [2^(14+b), 2^(15+b)) cycles, in the row of a kind
+            // of scan the bounded configuration does not launch (reflection rays: row 0, shadow rays: row 5)
+            int b = 31 - __builtin_clz(wk.t[5] | 1u) - 14;
+            b = b < 0 ? 0 : (b > 10 ? 10 : b);
+            atomicAdd(&A.work[(CONE == 4 ? 0 : 5) * RT_WORK_FIELDS + b], 1ull);
+        }
+        for (int f = 0; f < RT_WORK_FIELDS; f++) wk.v[f] = 0;
+#endif
         if (WORK && lane == 0 && A.work) {
             const int kind = (CONE == 1) ? 1 : (CONE == 4) ? 4 : (CONE == 2) ? cone_kind : (MODE == 0 ? 0 : 5);
 #pragma unroll
@@ -1549,6 +1608,15 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                 if (wk.v[f]) atomicAdd(&A.work[kind * RT_WORK_FIELDS + f], (unsigned long long)wk.v[f]);
         }
     }
+#ifdef RT_PHASE_CLOCK
+    if (WORK && lane == 0 && A.work && clk_sum[0] != 0) {
+        // (a launch holds one kind of scan, except that shadow launches mix the two kinds of light: booked under the plain kinds' rows' neighbour)
+        const int kind = (CONE == 1) ? 1 : (CONE == 4) ? 4 : (CONE == 2) ? 2 : (MODE == 0 ? 0 : 5);
+        for (int f = 0; f < 7; f++) atomicAdd(&A.work[kind * RT_WORK_FIELDS + f], clk_sum[f]);
+        atomicAdd(&A.work[kind * RT_WORK_FIELDS + 7], (unsigned long long)(RT_CLOCK() - clk_wave));
+        atomicAdd(&A.work[kind * RT_WORK_FIELDS + 8], 1ull);
+    }
+#endif
 }
 
 // One thread per listed (ray, triangle) pair.

@@ -1,0 +1,29 @@
+"""Milliseconds per frame by kind of scan (HIP events, streams serialised) and for the whole frame in the
+default configuration (two streams), teapot 4K depth 5 unless another scene is named.  One JSON line."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from raytracer_amd import Scene, abi
+from raytracer_amd.render import Renderer
+scene = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "scenes", "teapot.scene")
+w, h, d = (int(x) for x in sys.argv[2:5]) if len(sys.argv) > 4 else (3840, 2160, 5)
+n = 5
+r = Renderer(Scene.load(scene, w, h, d))
+for _ in range(2):
+    r.render_frame()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(n):
+    r.render_frame()
+torch.cuda.synchronize()
+frame = (time.perf_counter() - t0) / n * 1e3
+r.reset_stats()
+r.set_option(abi.RT_OPT_PROFILE, 1)
+for _ in range(n):
+    r.render_frame()
+st = r.stats()
+ms = {k: round(v / n, 3) for k, v in st["scan_ms"].items() if v}
+ms["exact"] = round(st["exact_ms"] / n, 3)
+print(json.dumps({"lib": os.path.basename(os.environ.get("RAYTRACER_AMD_LIB", "default")), "frame_ms": round(frame, 3), "ms": ms,
+                  "exact_tests": st["exact_tests"] // n}))
