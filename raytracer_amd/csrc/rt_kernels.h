@@ -1144,8 +1144,16 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
 #endif
     // tasks per wave to aim for (camera rays cost alike and want few, long tasks; the tasks of shadow and
     // reflection rays differ a lot in cost, and the launch ends with its longest one)
-    const unsigned int per_wave = CONE == 1 ? RT_TASKS_PER_WAVE_BOUNDED : CONE == 2 ? RT_TASKS_PER_WAVE_SHADOW
-                                : CONE == 4 ? RT_TASKS_PER_WAVE_ANY : 8u;
+    unsigned int per_wave = CONE == 1 ? RT_TASKS_PER_WAVE_BOUNDED : CONE == 2 ? RT_TASKS_PER_WAVE_SHADOW
+                          : CONE == 4 ? RT_TASKS_PER_WAVE_ANY : 8u;
+    // A launch with few blocks of rays (a deep level, one rank's share of an N-GPU frame) gets its tasks by cutting
+    // the triangle range, and every part loads the block's rays and builds their bundles again -- 40-60 % of
+    // such a task.  Two tasks per wave then: 2.33 -> 2.13 ms for one rank's eighth of the 4K frame, and the
+    // whole frame on one GPU gains as well (its deep levels), 7.62 -> 7.35 ms.
+#ifndef RT_TASKS_PER_WAVE_SMALL
+#define RT_TASKS_PER_WAVE_SMALL 2
+#endif
+    if (CONE && n_ray_blocks < 2u * n_waves) per_wave = RT_TASKS_PER_WAVE_SMALL;
     if (n_ray_blocks < per_wave * n_waves) {
         split = (int)((per_wave * n_waves + n_ray_blocks - 1) / n_ray_blocks);
         if (split > max_split) split = max_split;
@@ -1252,10 +1260,14 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
             if (MODE == 0 || !have_rays) {
                 have_rays = true;
                 L.on = 0;
-                // A real loop (not unrolled): one ray's double-precision temporaries are dead before
-                // the next ray's are born, so this prologue does not set the kernel's register count.
+                // A real loop (not fully unrolled): a ray's double-precision temporaries are dead before
+                // the next round's are born, so this prologue does not set the kernel's register count.
                 // The results are routed into the (statically indexed) register arrays by selects.
-#pragma unroll 1
+                // (two rays per round: two rays' loads in flight; four or all of them made the scans slower)
+#ifndef RT_RAY_LOAD_UNROLL
+#define RT_RAY_LOAD_UNROLL 2
+#endif
+#pragma unroll RT_RAY_LOAD_UNROLL
                 for (int r = 0; r < RPL; r++) {
                     // A slot past the end of the queue mirrors the queue's last ray: its candidates are
                     // dropped (bit r of L.on stays clear), so no per-slot thresholds are needed.

@@ -6,14 +6,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from raytracer_amd import Scene, abi
 from raytracer_amd.render import Renderer
+share = 1
+if "--share" in sys.argv:                      # the share of rank 0 of an N-GPU job (interleaved 16-row tiles) instead of the frame
+    i = sys.argv.index("--share")
+    share = int(sys.argv[i + 1])
+    del sys.argv[i:i + 2]
 scene = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "scenes", "teapot.scene")
 w, h, d = (int(x) for x in sys.argv[2:5]) if len(sys.argv) > 4 else (3840, 2160, 5)
 r = Renderer(Scene.load(scene, w, h, d))
-r.render_frame()
+def frame():
+    if share == 1:
+        r.render_frame()
+    else:
+        r.render_tiles(0, 16, share)
+frame()
 r.reset_stats()
 r.set_option(abi.RT_OPT_PROFILE, 1)
 r.set_option(abi.RT_OPT_WORK_COUNTERS, 1)
-r.render_frame()
+frame()
 st = r.stats()
 names = ["tasks", "wait_task", "rays", "judge", "batches", "flush", "task_total", "wave_life", "waves"]
 out = {}
