@@ -1153,9 +1153,15 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
 #ifndef RT_TASKS_PER_WAVE_SMALL
 #define RT_TASKS_PER_WAVE_SMALL 2
 #endif
-    if (CONE && n_ray_blocks < 2u * n_waves) per_wave = RT_TASKS_PER_WAVE_SMALL;
     if (n_ray_blocks < per_wave * n_waves) {
         split = (int)((per_wave * n_waves + n_ray_blocks - 1) / n_ray_blocks);
+        if (CONE && n_ray_blocks < 2u * n_waves) {
+            // (only where parts are short anyway: with parts of more than 2048 slots the scan outweighs the
+            // reloading, and a scene of a million triangles wants its many tasks back)
+            const int fewer = (int)((RT_TASKS_PER_WAVE_SMALL * n_waves + n_ray_blocks - 1) / n_ray_blocks);
+            const int keep_short = (NR + 2047) / 2048;
+            split = max(fewer, min(split, keep_short));
+        }
         if (split > max_split) split = max_split;
         // (a launch that cannot give every wave a task even so -- a few thousand rays, the deep
         // reflection levels -- lasts as long as its longest task: parts down to 128 triangles)
