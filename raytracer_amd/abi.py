@@ -13,6 +13,7 @@ RT_OK, RT_ERR_ARG, RT_ERR_DEVICE, RT_ERR_RANGE, RT_ERR_STATE = 0, -1, -2, -3, -4
 RT_OPT_EXACT_ONLY, RT_OPT_PROFILE, RT_OPT_PASS_PIXELS, RT_OPT_USE_BVH, RT_OPT_FILTER_FORM, RT_OPT_SHARED_CONSTANTS, RT_OPT_OVERLAP = 1, 2, 3, 4, 5, 6, 7
 RT_OPT_BOUNDING_TESTS = 8
 RT_OPT_WORK_COUNTERS = 9
+RT_OPT_SCAN_COPIES = 10
 SCAN_KINDS = ["plain_nearest", "camera", "shadow_point", "shadow_directional", "reflection", "plain_shadow"]
 
 

@@ -160,14 +160,17 @@ struct Workspace {
     double *lvl_phong = nullptr, *lvl_child = nullptr; // [levels][3][cap]
     uint32_t* counts = nullptr;                        // [levels + 2]
     uint32_t* hit_offsets = nullptr;                   // [aux_grid + 1]: k_hit_offsets -> k_hit
-    // [16 + rays]: the pair counter and the task counter (8 bytes each) in front of the per-ray
-    // flags, so that one fill clears all three before a launch; one set per kind of query
+    // [RT_FLAGS_HEADER + rays]: the pair list's fill counters and the task counter in front of the per-ray
+    // flags, so that one fill clears them all before a launch; one set per kind of query
     // ([0] nearest hit, [1] shadow) so that a level's shadow launches can run beside the next
     // level's nearest-hit launches
     uint8_t* ray_flags[2] = {nullptr, nullptr};
     size_t ray_flags_n[2] = {0, 0};
     unsigned long long* pairs[2] = {nullptr, nullptr};
     size_t pair_cap[2] = {0, 0};
+    // FP32 scan copies (RayQueue::scan, TraceArgs::shadow_scan); null when the workspace keeps none
+    float* scan[2] = {nullptr, nullptr};               // [9][cap], beside rayq[i]
+    float4* shadow_scan[2] = {nullptr, nullptr};       // [n_lights][cap], by level parity
 };
 
 struct rt_ctx {
@@ -190,6 +193,8 @@ struct rt_ctx {
     DevBuf<DevCounters> counters;
     DevBuf<unsigned long long> work;   // [RT_WORK_KINDS][RT_WORK_FIELDS], see WorkCount
     int work_counters = 0;             // RT_OPT_WORK_COUNTERS
+    int scan_copies = 1;               // RT_OPT_SCAN_COPIES
+    bool all_identity = false;         // every transform group is the identity (object space = world space)
 
     // workspace, sized for `ws.cap` rays per pass: one allocation, cut by carve_workspace
     Workspace ws;
@@ -260,10 +265,15 @@ struct rt_ctx {
 
 namespace {
 
-RayQueue queue_of(double* b, size_t cap) {
+// Queue i of a workspace; `scan`: with its FP32 scan copies (when the workspace keeps them).
+RayQueue queue_of(const Workspace& w, int i, bool scan) {
     RayQueue q;
+    double* b = w.rayq[i];
+    const size_t cap = w.cap;
     q.ox = b; q.oy = b + cap; q.oz = b + 2 * cap;
     q.dx = b + 3 * cap; q.dy = b + 4 * cap; q.dz = b + 5 * cap;
+    q.scan = scan ? w.scan[i] : nullptr;
+    q.scan_stride = (uint32_t)cap;
     return q;
 }
 
@@ -281,8 +291,11 @@ LevelStore level_of(const Workspace& w, int k) {
 // `pairs_per_ray` entries per ray of the largest launch of their kind (a few are typical; a
 // list that runs full sends its rays through the full reference-precision scan instead), at
 // least `min_pairs`, at most 2^28.
+#define RT_FLAGS_HEADER (RT_PAIR_LISTS * 128 + 16)     // bytes in front of a workspace's ray flags (see launch_trace)
+// `scan_copies`: also room for the FP32 scan copies of the rays (shadow rays: up to RT_SCAN_MAX_LIGHTS lights).
+#define RT_SCAN_MAX_LIGHTS 8
 size_t carve_workspace(Workspace* w, unsigned char* base, size_t cap, int levels, int n_lights, int aux_grid,
-                       size_t pairs_per_ray, size_t min_pairs) {
+                       size_t pairs_per_ray, size_t min_pairs, bool scan_copies) {
     size_t off = 0;
     auto take = [&](size_t bytes) -> unsigned char* {
         unsigned char* at = base ? base + off : nullptr;
@@ -307,10 +320,16 @@ size_t carve_workspace(Workspace* w, unsigned char* base, size_t cap, int levels
     t.hit_offsets = (uint32_t*)take(((size_t)aux_grid + 1) * sizeof(uint32_t));
     const size_t max_rays[2] = {cap, cap * (size_t)std::max(1, n_lights)};
     for (int m = 0; m < 2; m++) {
-        t.ray_flags_n[m] = max_rays[m] + 16;
+        t.ray_flags_n[m] = max_rays[m] + RT_FLAGS_HEADER;
         t.ray_flags[m] = (uint8_t*)take(t.ray_flags_n[m]);
         t.pair_cap[m] = std::min<size_t>(std::max<size_t>(max_rays[m] * pairs_per_ray, min_pairs), (size_t)1 << 28);
         t.pairs[m] = (unsigned long long*)take(t.pair_cap[m] * sizeof(unsigned long long));
+    }
+    if (scan_copies) {
+        for (int i = 0; i < 2; i++) {
+            t.scan[i] = (float*)take(9 * cap * sizeof(float));
+            if (n_lights >= 1 && n_lights <= RT_SCAN_MAX_LIGHTS) t.shadow_scan[i] = (float4*)take((size_t)n_lights * cap * sizeof(float4));
+        }
     }
     if (w) *w = t;
     return off;
@@ -339,7 +358,7 @@ int ensure_workspace(rt_ctx* c) {
         if (c->ev_hit.size() <= c->ev_phong.size()) c->ev_hit.push_back(e); else c->ev_phong.push_back(e);
     }
     // room for 16 listed pairs per ray of the largest launch (a few are typical), 8 B each
-    const size_t bytes = carve_workspace(nullptr, nullptr, want, levels, c->hs.n_lights, c->aux_grid, 16, (size_t)1 << 20);
+    const size_t bytes = carve_workspace(nullptr, nullptr, want, levels, c->hs.n_lights, c->aux_grid, 16, (size_t)1 << 20, true);
     HIP_TRY(hipDeviceSynchronize());          // no launch may still use the block released here
     c->ws = Workspace{};
     c->ws_block.release();
@@ -350,7 +369,7 @@ int ensure_workspace(rt_ctx* c) {
                                        " (lower RT_OPT_PASS_PIXELS)");
     }
     Workspace w;
-    carve_workspace(&w, c->ws_block.p, want, levels, c->hs.n_lights, c->aux_grid, 16, (size_t)1 << 20);
+    carve_workspace(&w, c->ws_block.p, want, levels, c->hs.n_lights, c->aux_grid, 16, (size_t)1 << 20, true);
     // (the last entry of hit_offsets counts finished blocks and must start at zero)
     e = hipMemset(w.hit_offsets, 0, ((size_t)c->aux_grid + 1) * sizeof(uint32_t));
     if (e != hipSuccess) {
@@ -422,14 +441,20 @@ int launch_trace(rt_ctx* c, const Workspace& W, TraceArgs A, hipStream_t st, siz
     A.graze_slots = c->graze_slots.p; A.graze_start = c->graze_start.p;
     if (MODE == 1 && light_bounds) A.plane_any = c->plane_any.p;
     A.cl_sphere = c->cl_sphere.p; A.cl_normal = c->cl_normal.p; A.n_clusters = c->n_clusters;
+    // (the header in front of the flags: RT_PAIR_LISTS fill counters on a 128-byte line each, then 16 bytes with
+    // the task counter and "some ray is flagged")
     A.pair_count = (unsigned long long*)W.ray_flags[MODE];
-    A.task_counter = (unsigned int*)(A.pair_count + 1);
-    A.any_flagged = A.task_counter + 1;           // (the 16-byte header: pair count, task counter, "some ray is flagged")
-    A.ray_flags = W.ray_flags[MODE] + 16; A.pairs = W.pairs[MODE];
+    A.task_counter = (unsigned int*)(W.ray_flags[MODE] + RT_FLAGS_HEADER - 8);
+    A.any_flagged = A.task_counter + 1;
+    A.ray_flags = W.ray_flags[MODE] + RT_FLAGS_HEADER; A.pairs = W.pairs[MODE];
     A.pair_cap = (unsigned int)W.pair_cap[MODE]; A.counters = c->counters.p; A.scan_all = c->force_exact;
+    // as many sub-lists as leave each at least 65536 entries (a flush appends up to 4096)
+    A.pair_lists = 1;
+    while (A.pair_lists < RT_PAIR_LISTS && W.pair_cap[MODE] / (2 * A.pair_lists) >= 65536) A.pair_lists *= 2;
+    A.pair_seg = (unsigned int)(W.pair_cap[MODE] / A.pair_lists);
     const bool work = c->work_counters && c->work.p;
     A.work = work ? c->work.p : nullptr;
-    HIP_TRY(hipMemsetAsync(W.ray_flags[MODE], 0, std::min(W.ray_flags_n[MODE], max_rays + 16), st));   // (no queue of the pass is longer)
+    HIP_TRY(hipMemsetAsync(W.ray_flags[MODE], 0, std::min(W.ray_flags_n[MODE], max_rays + RT_FLAGS_HEADER), st));   // (no queue of the pass is longer)
     if (!c->force_exact && c->hs.n_regular > 0) {
         int scan_kind = MODE == 0 ? 0 : 5;
         if (!c->use_bvh) {
@@ -543,6 +568,15 @@ int build_bvh(rt_ctx* c) {
     return 0;
 }
 
+// FP32 scan copies of the rays (RayQueue::scan, TraceArgs::shadow_scan): kept when the workspace has room for
+// them and the scans that read them will run.
+bool keeps_scan_copies(const rt_ctx* c, const Workspace& ws) {
+    return c->scan_copies && ws.scan[0] && !c->use_bvh && !c->force_exact && c->pretest && c->hs.n_regular > 0;
+}
+bool keeps_shadow_copies(const rt_ctx* c, const Workspace& ws) {
+    return ws.shadow_scan[0] && c->shared_consts && c->bound_lights.n > 0 && c->light_frame.n > 0;
+}
+
 // One pass: rows q0 .. q0+nrows of the pass's row sequence, nrows * width <= cap.
 // `ws`: the workspace to use (nrows * width <= ws.cap).  `side_work`: false keeps every launch on
 // the caller's stream and records no event (the entry point that allocates nothing).
@@ -552,7 +586,10 @@ int run_pass(rt_ctx* c, const Workspace& ws, PassDesc pd, int nrows, hipStream_t
     const int levels = ws.levels;
     const DevScene* dsc = c->d_scene.p;
     HIP_TRY(hipMemsetAsync(ws.counts, 0, (levels + 2) * sizeof(uint32_t), st));
-    RayQueue q[2] = {queue_of(ws.rayq[0], ws.cap), queue_of(ws.rayq[1], ws.cap)};
+    // FP32 scan copies of the rays for the bounded scans (RayQueue::scan): written by k_primary / k_hit when the
+    // workspace has room for them and the scans that read them will run
+    const bool scan = keeps_scan_copies(c, ws), scan_shadow = scan && keeps_shadow_copies(c, ws);
+    RayQueue q[2] = {queue_of(ws, 0, scan), queue_of(ws, 1, scan)};
     hipLaunchKernelGGL(k_primary, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, dsc, pd, n_pix, q[0], ws.keys[0],
                        ws.pixel_of_ray, c->frame, ws.counts);
     HIP_TRY(hipGetLastError());
@@ -575,6 +612,7 @@ int run_pass(rt_ctx* c, const Workspace& ws, PassDesc pd, int nrows, hipStream_t
         TraceArgs ta{};
         ta.rays = q[cur]; ta.n_items = ws.counts + k; ta.keys = ws.keys[cur];
         ta.occl_words = ws.occl_words;
+        ta.scan_nearest = (scan && c->all_identity) ? 1 : 0;
         int rc = launch_trace<0>(c, ws, ta, st, (size_t)n_pix, k == 0, side_work);
         if (rc) return rc;
 
@@ -583,6 +621,8 @@ int run_pass(rt_ctx* c, const Workspace& ws, PassDesc pd, int nrows, hipStream_t
         ha.sc = dsc; ha.cur = q[cur]; ha.next = q[nxt]; ha.keys = ws.keys[cur]; ha.next_keys = ws.keys[nxt];
         ha.n_rays = ws.counts + k; ha.hit_offsets = ws.hit_offsets; ha.lvl = lvl; ha.aux = aux;
         ha.occluded = occl; ha.occl_words = ws.occl_words;
+        ha.shadow_scan = scan_shadow ? ws.shadow_scan[cur] : nullptr; ha.shadow_stride = (uint32_t)ws.cap;
+        ha.light_frame = c->light_frame.p;
         hipLaunchKernelGGL(k_hit_offsets, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, (const unsigned long long*)ws.keys[cur],
                            (const uint32_t*)(ws.counts + k), ws.hit_offsets, ws.counts + k + 1);
         hipLaunchKernelGGL(k_hit, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, ha);
@@ -596,6 +636,7 @@ int run_pass(rt_ctx* c, const Workspace& ws, PassDesc pd, int nrows, hipStream_t
             TraceArgs sa{};
             sa.rays = q[nxt]; sa.n_items = ws.counts + k + 1; sa.source_obj = lvl.obj;
             sa.occluded = occl; sa.occl_words = ws.occl_words;
+            sa.shadow_scan = scan_shadow ? ws.shadow_scan[cur] : nullptr; sa.shadow_stride = (uint32_t)ws.cap;
             rc = launch_trace<1>(c, ws, sa, sb, (size_t)n_pix * (size_t)std::max(1, c->hs.n_lights), false, side_work);
             if (rc) return rc;
         }
@@ -782,6 +823,8 @@ int install_filter(rt_ctx* c, int robust) {
     }
 
     c->h_groups = groups;
+    c->all_identity = true;
+    for (const Group& g : groups) if (!g.identity) c->all_identity = false;
     c->h_centroid_box.assign(6 * groups.size(), 0.f);
     for (size_t gi = 0; gi < groups.size(); gi++) {
         float* bx = &c->h_centroid_box[6 * gi];
@@ -1546,6 +1589,7 @@ int rt_set_option(rt_ctx* c, int option, int64_t value) {
         case RT_OPT_SHARED_CONSTANTS: c->shared_consts = value ? 1 : 0; return 0;
         case RT_OPT_OVERLAP: c->overlap = value ? 1 : 0; return 0;
         case RT_OPT_WORK_COUNTERS: c->work_counters = value ? 1 : 0; return 0;
+        case RT_OPT_SCAN_COPIES: c->scan_copies = value ? 1 : 0; return 0;
         case RT_OPT_BOUNDING_TESTS: c->pretest = value ? 1 : 0; c->pretest_any = value == 1 ? 1 : 0; return 0;
         case RT_OPT_USE_BVH:
             if (value) {
@@ -1587,13 +1631,13 @@ int rt_render_tile_noalloc(rt_ctx* c, int y0, int rows, void* stream) {
     const int W = c->hs.width, levels = c->hs.max_depth + 1, lights = c->hs.n_lights;
     // the whole tile is one pass; 8 listed pairs per ray (a list that runs full costs time, not pixels)
     const size_t pixels = (size_t)rows * (size_t)W;
-    const size_t need = carve_workspace(nullptr, nullptr, pixels, levels, lights, c->aux_grid, 8, 0);
+    const size_t need = carve_workspace(nullptr, nullptr, pixels, levels, lights, c->aux_grid, 8, 0, false);
     if (need > RT_SCRATCH_BYTES || pixels * (size_t)std::max(1, lights) >= ((size_t)1 << 31)) {
         // largest row count of this scene that fits (the size grows monotonically with the rows)
         int lo = 0, hi = rows;
         while (lo + 1 < hi) {
             const int mid = lo + (hi - lo) / 2;
-            if (carve_workspace(nullptr, nullptr, (size_t)mid * W, levels, lights, c->aux_grid, 8, 0) <= RT_SCRATCH_BYTES) lo = mid; else hi = mid;
+            if (carve_workspace(nullptr, nullptr, (size_t)mid * W, levels, lights, c->aux_grid, 8, 0, false) <= RT_SCRATCH_BYTES) lo = mid; else hi = mid;
         }
         char msg[256];
         snprintf(msg, sizeof msg, "rt_render_tile_noalloc: %d rows of %d pixels need %zu bytes of workspace, the static workspace "
@@ -1603,7 +1647,7 @@ int rt_render_tile_noalloc(rt_ctx* c, int y0, int rows, void* stream) {
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     Workspace ws;
-    carve_workspace(&ws, base, pixels, levels, lights, c->aux_grid, 8, 0);
+    carve_workspace(&ws, base, pixels, levels, lights, c->aux_grid, 8, 0, false);
     // The array keeps whatever the previous call left in it, at whatever offsets that call's sizes
     // put it: the one slice that must start at zero (the count of finished blocks behind the
     // hit offsets) is cleared here; queue lengths, counters and flags are cleared by the pass.
@@ -1634,12 +1678,14 @@ int rt_primary_hits(rt_ctx* c, int y0, int rows, uint64_t* keys, size_t count) {
         const int n_pix = nrows * W;
         PassDesc pd{y0, rows, rows, q0};
         HIP_TRY(hipMemsetAsync(ws.counts, 0, (ws.levels + 2) * sizeof(uint32_t), st));
-        RayQueue q = queue_of(ws.rayq[0], ws.cap);
+        const bool scan = keeps_scan_copies(c, ws);
+        RayQueue q = queue_of(ws, 0, scan);
         hipLaunchKernelGGL(k_primary, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, dsc, pd, n_pix, q, ws.keys[0],
                            ws.pixel_of_ray, c->frame, ws.counts);
         HIP_TRY(hipGetLastError());
         TraceArgs ta{};
         ta.rays = q; ta.n_items = ws.counts; ta.keys = ws.keys[0]; ta.occl_words = ws.occl_words;
+        ta.scan_nearest = (scan && c->all_identity) ? 1 : 0;
         rc = launch_trace<0>(c, ws, ta, st, (size_t)n_pix, true);
         if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(st));
@@ -1687,12 +1733,14 @@ int rt_bounce_probe(rt_ctx* c, int y0, int rows, double* point, double* refl, ui
         const int n_pix = nrows * W;
         PassDesc pd{y0, rows, rows, q0};
         HIP_TRY(hipMemsetAsync(ws.counts, 0, (ws.levels + 2) * sizeof(uint32_t), st));
-        RayQueue q[2] = {queue_of(ws.rayq[0], ws.cap), queue_of(ws.rayq[1], ws.cap)};
+        const bool scan = keeps_scan_copies(c, ws), scan_shadow = scan && keeps_shadow_copies(c, ws);
+        RayQueue q[2] = {queue_of(ws, 0, scan), queue_of(ws, 1, scan)};
         hipLaunchKernelGGL(k_primary, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, dsc, pd, n_pix, q[0], ws.keys[0],
                            ws.pixel_of_ray, c->frame, ws.counts);
         HIP_TRY(hipGetLastError());
         TraceArgs ta{};
         ta.rays = q[0]; ta.n_items = ws.counts; ta.keys = ws.keys[0]; ta.occl_words = words;
+        ta.scan_nearest = (scan && c->all_identity) ? 1 : 0;
         rc = launch_trace<0>(c, ws, ta, st, (size_t)n_pix, true);
         if (rc) return rc;
         LevelStore lvl = level_of(ws, 0);
@@ -1704,6 +1752,8 @@ int rt_bounce_probe(rt_ctx* c, int y0, int rows, double* point, double* refl, ui
         ha.sc = dsc; ha.cur = q[0]; ha.next = q[1]; ha.keys = ws.keys[0]; ha.next_keys = ws.keys[1];
         ha.n_rays = ws.counts; ha.hit_offsets = ws.hit_offsets; ha.lvl = lvl; ha.aux = aux;
         ha.occluded = ws.occluded[0]; ha.occl_words = words;
+        ha.shadow_scan = scan_shadow ? ws.shadow_scan[0] : nullptr; ha.shadow_stride = (uint32_t)ws.cap;
+        ha.light_frame = c->light_frame.p;
         hipLaunchKernelGGL(k_hit_offsets, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, (const unsigned long long*)ws.keys[0],
                            (const uint32_t*)ws.counts, ws.hit_offsets, ws.counts + 1);
         hipLaunchKernelGGL(k_hit, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, ha);
@@ -1712,12 +1762,14 @@ int rt_bounce_probe(rt_ctx* c, int y0, int rows, double* point, double* refl, ui
             TraceArgs sa{};
             sa.rays = q[1]; sa.n_items = ws.counts + 1; sa.source_obj = lvl.obj;
             sa.occluded = ws.occluded[0]; sa.occl_words = words;
+            sa.shadow_scan = scan_shadow ? ws.shadow_scan[0] : nullptr; sa.shadow_stride = (uint32_t)ws.cap;
             rc = launch_trace<1>(c, ws, sa, st, (size_t)n_pix * (size_t)std::max(1, c->hs.n_lights));
             if (rc) return rc;
         }
         if (keys1) {
             TraceArgs tb{};
             tb.rays = q[1]; tb.n_items = ws.counts + 1; tb.keys = ws.keys[1]; tb.occl_words = words;
+            tb.scan_nearest = (scan && c->all_identity) ? 1 : 0;
             rc = launch_trace<0>(c, ws, tb, st, (size_t)n_pix, false);
             if (rc) return rc;
         }

@@ -42,11 +42,58 @@
                                 // task ask for fewer triangles than 512; the scans of camera and shadow rays lose by it)
 #endif
 // a staged candidate (u16) = triangle index relative to a chunk base | ray slot << shift
+#define RT_PAIR_LISTS 64        // sub-lists of the pair list at most (see TraceArgs::pair_count)
 #define RT_SLOT_SHIFT(RPL) ((RPL) <= 2 ? 15 : ((RPL) <= 4 ? 14 : 13))
 
 struct RayQueue {               // structure of arrays, one entry per ray
     double *ox, *oy, *oz, *dx, *dy, *dz;
+    // FP32 scan copies (null: none kept): what the bounded scans of k_filter hold per ray -- origin, direction
+    // and the three per-ray values of the bounding test -- written once by the kernel that makes the ray
+    // (k_primary, k_hit) instead of being derived from the doubles again by every task that scans a part of
+    // the triangles for it.  Three arrays of scan_stride entries, one after the other: float4 (px py pz hx),
+    // float4 (vx vy vz hy), float hz -- three coalesced loads per ray from three uniform bases.
+    float* scan;
+    uint32_t scan_stride;
 };
+__device__ __forceinline__ void scan_store(const RayQueue& q, unsigned int i, float px, float py, float pz, float vx, float vy,
+                                           float vz, float hx, float hy, float hz) {
+    float4* a = (float4*)q.scan;
+    float4* b = a + q.scan_stride;
+    float* c = (float*)(b + q.scan_stride);
+    a[i] = make_float4(px, py, pz, hx);
+    b[i] = make_float4(vx, vy, vz, hy);
+    c[i] = hz;
+}
+
+// The per-ray values of the bounding tests, in ONE place: the kernels that write the scan copies and the
+// scan's own conversion of the doubles must produce the same bits (the filter's margins are derived for
+// exactly these roundings, and the two paths are held to equal pair lists by the tests).
+// Camera rays (cone test): the unit direction.
+__device__ __forceinline__ void scan_h_camera(double vx, double vy, double vz, float* ux, float* uy, float* uz) {
+    const double inv_len = 1.0 / sqrt(vx * vx + vy * vy + vz * vz);
+    *ux = (float)(vx * inv_len); *uy = (float)(vy * inv_len); *uz = (float)(vz * inv_len);
+}
+// Rays with nothing in common (distance of a sphere's centre from the ray's line, expanded): P.V, |P|^2,
+// 1 / |V|^2 from the rounded values the test multiplies.
+__device__ __forceinline__ void scan_h_any(float fx, float fy, float fz, float gx, float gy, float gz,
+                                           float* ux, float* uy, float* uz) {
+    *ux = (float)((double)fx * gx + (double)fy * gy + (double)fz * gz);
+    *uy = (float)((double)fx * fx + (double)fy * fy + (double)fz * fz);
+    *uz = (float)(1.0 / ((double)gx * gx + (double)gy * gy + (double)gz * gz));
+}
+// Shadow ray towards a point light: distance to the light, rounded up.
+__device__ __forceinline__ float scan_len_point(const double* light_pos, double px, double py, double pz) {
+    const double lx = light_pos[0] - px, ly = light_pos[1] - py, lz = light_pos[2] - pz;
+    return (float)(sqrt(lx * lx + ly * ly + lz * lz) * (1.0 + 1e-6));
+}
+// Shadow ray towards a directional light: its origin in the light's plane (frame F: e1, e2, offsets), and the
+// square of that point.
+__device__ __forceinline__ void scan_plane_point(const double* F, double px, double py, double pz,
+                                                 float* ux, float* uy, float* uz) {
+    *ux = (float)(px * F[0] + py * F[1] + pz * F[2] + F[6]);
+    *uy = (float)(px * F[3] + py * F[4] + pz * F[5] + F[7]);
+    *uz = (float)((double)*ux * (double)*ux + (double)*uy * (double)*uy);
+}
 
 struct LevelStore {             // one entry per hit of a level
     int32_t* parent;            // index of the ray in this level's queue (= hit index one level up, or the pixel)
@@ -119,6 +166,11 @@ k_primary(const DevScene* __restrict__ sc, PassDesc pd, int n_pix, RayQueue q,
         d3 dir = sub3(c, eye);
         q.ox[p] = eye.x; q.oy[p] = eye.y; q.oz[p] = eye.z;
         q.dx[p] = dir.x; q.dy[p] = dir.y; q.dz[p] = dir.z;
+        if (q.scan) {
+            float ux, uy, uz;
+            scan_h_camera(dir.x, dir.y, dir.z, &ux, &uy, &uz);
+            scan_store(q, (unsigned int)p, (float)eye.x, (float)eye.y, (float)eye.z, (float)dir.x, (float)dir.y, (float)dir.z, ux, uy, uz);
+        }
         keys[p] = RT_MISS_KEY;
         int pix = (H - 1 - y) * W + x;          // row 0 of the frame is the top scanline (raytracer.cpp:225)
         pixel_of_ray[p] = pix;
@@ -152,7 +204,12 @@ struct TraceArgs {
     int32_t scan_all;                    // k_brute: 1 = test every triangle for every ray (filter switched off)
     uint8_t* ray_flags;                  // per ray: 1 = k_brute must scan every triangle for it
     unsigned long long* pairs;           // (ray << 32) | exact-record slot
-    unsigned long long* pair_count;      // pairs appended so far (may run past pair_cap: the surplus is dropped)
+    // The pair list is cut into pair_lists (a power of two, at most RT_PAIR_LISTS) equal sub-lists of pair_seg
+    // entries, each with a fill counter on a 128-byte line of its own (pair_count[16 * l]): a flush picks one by a
+    // hash of its rays and its chunk.  (One list with one counter had every flush of every wave of a launch
+    // queue at one address of one L2 channel: 0.26 ms of the 0.66 ms camera-ray scan of a 4K frame.)
+    unsigned long long* pair_count;      // per sub-list: pairs appended so far (may run past pair_seg: the surplus is dropped)
+    unsigned int pair_lists, pair_seg;
     unsigned int* task_counter;          // k_filter: next task to hand out (zeroed before the launch)
     unsigned int* any_flagged;           // set to 1 by whoever sets a ray flag (zeroed before the launch): lets k_brute
                                          // leave at once when no ray is flagged and the scene has nothing else for it
@@ -185,6 +242,13 @@ struct TraceArgs {
     const float* cl_sphere;              // [n_clusters + 1][4]   centre, radius
     const float* cl_normal;              // [n_clusters + 1][4]   unit mean normal N, sine of the largest angle between N and a member's normal
     int32_t n_clusters;
+    // FP32 scan copies (see RayQueue::scan).  MODE 0: rays.scan may be used (every group's transform is the
+    // identity).  MODE 1: per (light, hit) of the launch, [light * shadow_stride + hit]: point light -- unit
+    // direction to the light and the distance (rounded up); directional light -- the origin in the light's
+    // plane and the square of that point; null: none kept.  The origins are rays.scan's.
+    int32_t scan_nearest;
+    const float4* shadow_scan;
+    uint32_t shadow_stride;
     unsigned long long* work;            // k_filter<..., WORK = true>: [RT_WORK_KINDS][RT_WORK_FIELDS] executed-work counters
 };
 
@@ -449,11 +513,15 @@ __device__ __forceinline__ int flush_candidates(const TraceArgs& A, const unsign
     // instead of one record and one ray from anywhere per lane.
     int total = n_cand, most = n_cand;
     for (int off = 32; off > 0; off >>= 1) { total += __shfl_xor(total, off); most = max(most, __shfl_xor(most, off)); }
-    const unsigned long long base = wave_append(A.pair_count, (unsigned int)total, lane);
-    if (base + (unsigned int)total > A.pair_cap) {
-        // List full: every ray of this lane that has a candidate gets the full scan instead.
+    // (which sub-list: any spread will do; this one sends a task's flushes to different lists and neighbouring tasks' too)
+    // (ray0 is the lane's first ray: lane 0's value for the whole wave)
+    const unsigned int list = (((unsigned int)__builtin_amdgcn_readfirstlane((int)ray0) >> 6) * 5u + ((unsigned int)cbeg >> 6) * 3u + blockIdx.x) & (A.pair_lists - 1u);
+    unsigned long long* const pairs = A.pairs + (size_t)list * A.pair_seg;
+    const unsigned long long base = wave_append(A.pair_count + 16 * list, (unsigned int)total, lane);
+    if (base + (unsigned int)total > A.pair_seg) {
+        // Sub-list full: every ray of this lane that has a candidate gets the full scan instead.
         // Entries that still fit are written all the same (they are valid pairs), so the list
-        // has no unwritten slot below pair_cap.
+        // has no unwritten slot below its fill (capped at pair_seg).
 #pragma unroll
         for (int r = 0; r < RPL; r++) {
             const unsigned int ray = ray0 + r * RT_WAVE;
@@ -465,11 +533,11 @@ __device__ __forceinline__ int flush_candidates(const TraceArgs& A, const unsign
         const bool have = k < n_cand;
         const unsigned long long holders = __ballot(have);
         const unsigned long long mine = at + (unsigned int)__popcll(holders & ((1ull << lane) - 1ull));
-        if (have && mine < A.pair_cap) {
+        if (have && mine < A.pair_seg) {
             const unsigned int e = my_cand[k * RT_BLOCK];
             const unsigned int r = e >> SLOT_SHIFT;
             const unsigned int slot = (unsigned int)cbeg + (e & ((1u << SLOT_SHIFT) - 1u));
-            A.pairs[mine] = ((unsigned long long)(ray0 + r * RT_WAVE) << 32) | slot;
+            pairs[mine] = ((unsigned long long)(ray0 + r * RT_WAVE) << 32) | slot;
         }
         at += (unsigned int)__popcll(holders);
     }
@@ -1183,6 +1251,7 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
 #ifdef RT_PHASE_CLOCK
     const unsigned int clk_wave = RT_CLOCK();
     unsigned long long clk_sum[7] = {0, 0, 0, 0, 0, 0, 0};      // tasks, then the six phases: flushed once per wave
+    unsigned long long clk_loop = 0;                            // the ray-loading loop alone (part of phase 2)
 #endif
     for (;;) {
 #ifdef RT_PHASE_CLOCK
@@ -1266,12 +1335,27 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
             if (MODE == 0 || !have_rays) {
                 have_rays = true;
                 L.on = 0;
-                // A real loop (not fully unrolled): a ray's double-precision temporaries are dead before
-                // the next round's are born, so this prologue does not set the kernel's register count.
+                const bool copies = CONE != 0 && A.rays.scan != nullptr &&
+                                    (MODE == 0 ? (A.scan_nearest != 0 && ident) : (A.shadow_scan != nullptr));
+                // The FP32 scan copies (RayQueue::scan) when the launch has them: three loads per ray, no
+                // double-precision arithmetic.  Otherwise the ray's doubles are converted here.
+                const float4* SA = (const float4*)A.rays.scan;
+                const float4* SB = SA + A.rays.scan_stride;
+                const float* SC = (const float*)(SB + A.rays.scan_stride);
+                float udx = 0.f, udy = 0.f, udz = 1.f;        // directional light: the direction every ray of the task has
+                if (copies && CONE == 2 && cone_kind == 3) {
+                    const d3 dv = nrm3(neg3(ld3(sc->lights[light].pos)));      // Light::lightRay (raytracer.cpp:113-117)
+                    udx = (float)dv.x; udy = (float)dv.y; udz = (float)dv.z;
+                }
+                // A real loop (not fully unrolled): a ray's temporaries are dead before the next round's are
+                // born, so this prologue does not set the kernel's register count.
                 // The results are routed into the (statically indexed) register arrays by selects.
                 // (two rays per round: two rays' loads in flight; four or all of them made the scans slower)
 #ifndef RT_RAY_LOAD_UNROLL
 #define RT_RAY_LOAD_UNROLL 2
+#endif
+#ifdef RT_PHASE_CLOCK
+                const unsigned int clk_r0 = RT_CLOCK();
 #endif
 #pragma unroll RT_RAY_LOAD_UNROLL
                 for (int r = 0; r < RPL; r++) {
@@ -1279,34 +1363,41 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                     // dropped (bit r of L.on stays clear), so no per-slot thresholds are needed.
                     const unsigned int ray = ray0 + r * RT_WAVE;
                     const bool valid = ray < ray_end;
-                    d3 pos, vec;
-                    int source;
-                    load_world_ray<MODE>(A, sc, valid ? ray : ray_end - 1, n_hits, &pos, &vec, &source);
-                    to_object_space(X, ident, &pos, &vec);
-                    float fx = (float)pos.x, fy = (float)pos.y, fz = (float)pos.z;
-                    float gx = (float)vec.x, gy = (float)vec.y, gz = (float)vec.z;
+                    const unsigned int at = valid ? ray : ray_end - 1;
+                    float fx, fy, fz, gx, gy, gz, ux = 0.f, uy = 0.f, uz = 1.f, len = 0.f;
+                    float rdx = 0.f, rdy = 0.f, rdz = 1.f;      // CONE 2, directional light: the ray's direction
+                    if (copies) {
+                        if (MODE == 0) {
+                            const float4 a = SA[at], b = SB[at];
+                            fx = a.x; fy = a.y; fz = a.z; gx = b.x; gy = b.y; gz = b.z;
+                            if (CONE == 1 || CONE == 4) { ux = a.w; uy = b.w; uz = SC[at]; }
+                        } else {
+                            const unsigned int hit = at - (unsigned int)light * n_hits;     // (a block never holds rays towards two lights)
+                            const float4 a = SA[hit];
+                            const float4 rec = A.shadow_scan[(size_t)light * A.shadow_stride + hit];
+                            fx = a.x; fy = a.y; fz = a.z;
+                            gx = rec.x; gy = rec.y; gz = rec.z; len = rec.w;
+                            if (cone_kind == 3) { ux = rec.x; uy = rec.y; uz = rec.z; gx = udx; gy = udy; gz = udz; }
+                        }
+                        rdx = gx; rdy = gy; rdz = gz;
+                    } else {
+                        d3 pos, vec;
+                        int source;
+                        load_world_ray<MODE>(A, sc, at, n_hits, &pos, &vec, &source);
+                        to_object_space(X, ident, &pos, &vec);
+                        fx = (float)pos.x; fy = (float)pos.y; fz = (float)pos.z;
+                        gx = (float)vec.x; gy = (float)vec.y; gz = (float)vec.z;
+                        rdx = gx; rdy = gy; rdz = gz;
+                        if (CONE == 1) scan_h_camera(vec.x, vec.y, vec.z, &ux, &uy, &uz);
+                        // (directional light: the origin in the light's plane -- coordinates about the scene's centre -- and its square)
+                        if (CONE == 2 && cone_kind == 3) scan_plane_point(A.light_frame + 8 * (size_t)light, pos.x, pos.y, pos.z, &ux, &uy, &uz);
+                        if (CONE == 2 && cone_kind == 2) len = scan_len_point(sc->lights[light].pos, pos.x, pos.y, pos.z);
+                    }
                     // Outside the bounds the margins were derived for (or NaN): the ray takes the
                     // full reference-precision scan of k_brute instead of the filter.
                     const bool trusted = fabsf(fx) <= ob && fabsf(fy) <= ob && fabsf(fz) <= ob &&
                                          (gx * gx + gy * gy + gz * gz) <= vb;
-                    float ux = 0.f, uy = 0.f, uz = 1.f;
-                    if (CONE == 1) {
-                        const double inv_len = 1.0 / sqrt(vec.x * vec.x + vec.y * vec.y + vec.z * vec.z);
-                        ux = (float)(vec.x * inv_len); uy = (float)(vec.y * inv_len); uz = (float)(vec.z * inv_len);
-                    }
-                    if (CONE == 2 && cone_kind == 3) {
-                        // the origin in the light's plane (coordinates about the scene's centre), and its square
-                        const double* F = A.light_frame + 8 * (size_t)light;
-                        ux = (float)(pos.x * F[0] + pos.y * F[1] + pos.z * F[2] + F[6]);
-                        uy = (float)(pos.x * F[3] + pos.y * F[4] + pos.z * F[5] + F[7]);
-                        uz = (float)((double)ux * (double)ux + (double)uy * (double)uy);
-                    }
-                    if (CONE == 2 && cone_kind == 2) {
-                        const DevLight& lt = sc->lights[light];
-                        const double lx = lt.pos[0] - pos.x, ly = lt.pos[1] - pos.y, lz = lt.pos[2] - pos.z;
-                        const float len = (float)(sqrt(lx * lx + ly * ly + lz * lz) * (1.0 + 1e-6));
-                        if (valid) reach_max = fmaxf(reach_max, len);          // (a NaN drops out; such a ray is flagged below)
-                    }
+                    if (CONE == 2 && cone_kind == 2 && valid) reach_max = fmaxf(reach_max, len);   // (a NaN drops out; such a ray is flagged below)
                     if (CONE == 2 && valid && trusted) {
                         box_lo[0] = fminf(box_lo[0], fx); box_lo[1] = fminf(box_lo[1], fy); box_lo[2] = fminf(box_lo[2], fz);
                         box_hi[0] = fmaxf(box_hi[0], fx); box_hi[1] = fmaxf(box_hi[1], fy); box_hi[2] = fmaxf(box_hi[2], fz);
@@ -1317,16 +1408,13 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                         if (CONE != 1) { fx = 0.f; fy = 0.f; fz = 0.f; }
                         gx = 0.f; gy = 0.f; gz = 1.f;
                     }
-                    if (CONE == 4) {
-                        // per-ray parts of the expanded distance test, from the rounded values the test multiplies
-                        ux = (float)((double)fx * gx + (double)fy * gy + (double)fz * gz);
-                        uy = (float)((double)fx * fx + (double)fy * fy + (double)fz * fz);
-                        uz = (float)(1.0 / ((double)gx * gx + (double)gy * gy + (double)gz * gz));
-                    }
+                    // (per-ray parts of the expanded distance test, from the rounded values the test multiplies;
+                    // the copies hold them for the ray's own values)
+                    if (CONE == 4 && (!copies || !trusted)) scan_h_any(fx, fy, fz, gx, gy, gz, &ux, &uy, &uz);
                     if (CONE == 2 && cone_kind == 3) {
                         // Every ray of the task has the light's direction (kept in scalar registers);
                         // the direction slots carry the origin in the light's plane instead.
-                        if (valid || r == 0) { dir_x = (float)vec.x; dir_y = (float)vec.y; dir_z = (float)vec.z; }
+                        if (valid || r == 0) { dir_x = rdx; dir_y = rdy; dir_z = rdz; }
                         gx = ux; gy = uy; gz = uz;
                     }
                     if (valid && trusted) L.on |= 1u << r;
@@ -1344,6 +1432,9 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                         }
                     }
                 }
+#ifdef RT_PHASE_CLOCK
+                if (g == 0) { asm volatile("" :: "v"(L.px[0]), "v"(L.vz[RPL / 2 - 1])); wk.t[6] = RT_CLOCK() - clk_r0; }
+#endif
             }
             PlaneGuard guard = {};
             if (CONE == 4) { guard.planes = A.plane_any; guard.cl_bounds = A.cl_sphere; guard.cl_normals = A.cl_normal; guard.qsh = (const __attribute__((address_space(3))) float*)bundle_sh; }
@@ -1610,6 +1701,7 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
         wk.t[5] = RT_CLOCK() - clk_t0;
         clk_sum[0] += 1;
         for (int f = 0; f < 6; f++) clk_sum[1 + f] += wk.t[f];
+        clk_loop += wk.t[6];
         if (WORK && lane == 0 && A.work && (CONE == 4 || CONE == 2)) {
             // histogram of task durations: bucket b holds tasks of [2^(14+b), 2^(15+b)) cycles, in the row of a kind
             // of scan the bounded configuration does not launch (reflection rays: row 0, shadow rays: row 5)
@@ -1633,6 +1725,7 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
         for (int f = 0; f < 7; f++) atomicAdd(&A.work[kind * RT_WORK_FIELDS + f], clk_sum[f]);
         atomicAdd(&A.work[kind * RT_WORK_FIELDS + 7], (unsigned long long)(RT_CLOCK() - clk_wave));
         atomicAdd(&A.work[kind * RT_WORK_FIELDS + 8], 1ull);
+        atomicAdd(&A.work[kind * RT_WORK_FIELDS + 9], clk_loop);
     }
 #endif
 }
@@ -1641,15 +1734,32 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
 template <int MODE>
 __global__ void __launch_bounds__(RT_BLOCK)
 k_exact_pairs(const DevScene* __restrict__ sc, const TriExact* __restrict__ exact, TraceArgs A) {
-    const unsigned long long listed = *A.pair_count;
-    const unsigned int n = listed < A.pair_cap ? (unsigned int)listed : A.pair_cap;
+    // the sub-lists one after the other: first[l] = entries in the sub-lists before l
+    __shared__ unsigned int first[RT_PAIR_LISTS + 1];
+    if (threadIdx.x < RT_PAIR_LISTS) {
+        unsigned long long listed = 0;
+        if (threadIdx.x < A.pair_lists) listed = A.pair_count[16 * threadIdx.x];
+        first[threadIdx.x + 1] = listed < A.pair_seg ? (unsigned int)listed : A.pair_seg;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int sum = 0;
+        first[0] = 0;
+        for (int l = 1; l <= RT_PAIR_LISTS; l++) { sum += first[l]; first[l] = sum; }
+    }
+    __syncthreads();
+    const unsigned int n = first[RT_PAIR_LISTS];
     const unsigned int n_lights = sc->n_lights;
     const unsigned int n_hits = *A.n_items;
     const unsigned int n_rays = (MODE == 0) ? n_hits : n_hits * n_lights;
     const unsigned int n_regular = (unsigned int)sc->n_regular;
     const float eps = (MODE == 0) ? sc->eps : sc->shadow_eps;
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const unsigned long long pr = A.pairs[i];
+        unsigned int l = 0;
+#pragma unroll
+        for (unsigned int step = RT_PAIR_LISTS / 2; step > 0; step >>= 1)
+            if (first[l + step] <= i) l += step;
+        const unsigned long long pr = A.pairs[(size_t)l * A.pair_seg + (i - first[l])];
         const unsigned int ray = (unsigned int)(pr >> 32), slot = (unsigned int)pr;
         // Every entry below n was written by this launch's producers; the check only keeps a
         // producer bug from turning into an out-of-range access.
@@ -1802,6 +1912,9 @@ struct HitArgs {
     HitAux aux;
     uint32_t* occluded;
     int32_t occl_words;
+    float4* shadow_scan;                 // see TraceArgs (null: none kept); written for every light
+    uint32_t shadow_stride;
+    const double* light_frame;           // [n_lights][8], directional lights (see TraceArgs)
 };
 
 // The hits keep the order of their rays (ray i before ray j => its hit before j's): rays that
@@ -1951,6 +2064,29 @@ k_hit(HitArgs A) {
         refl = nrm3(refl);
         A.next.ox[h] = point.x; A.next.oy[h] = point.y; A.next.oz[h] = point.z;
         A.next.dx[h] = refl.x; A.next.dy[h] = refl.y; A.next.dz[h] = refl.z;
+        if (A.next.scan) {
+            const float fx = (float)point.x, fy = (float)point.y, fz = (float)point.z;
+            const float gx = (float)refl.x, gy = (float)refl.y, gz = (float)refl.z;
+            float ux, uy, uz;
+            scan_h_any(fx, fy, fz, gx, gy, gz, &ux, &uy, &uz);
+            scan_store(A.next, h, fx, fy, fz, gx, gy, gz, ux, uy, uz);
+            if (A.shadow_scan) {
+                for (int l = 0; l < sc->n_lights; l++) {
+                    const DevLight& lt = sc->lights[l];
+                    float4 rec;
+                    if (lt.is_point) {
+                        // Light::lightRay (raytracer.cpp:108-119): the same expressions as load_world_ray<1>
+                        const d3 dir = nrm3(sub3(ld3(lt.pos), point));
+                        rec = make_float4((float)dir.x, (float)dir.y, (float)dir.z, scan_len_point(lt.pos, point.x, point.y, point.z));
+                    } else {
+                        float px, py, pz;
+                        scan_plane_point(A.light_frame + 8 * (size_t)l, point.x, point.y, point.z, &px, &py, &pz);
+                        rec = make_float4(px, py, pz, 0.0f);
+                    }
+                    A.shadow_scan[(size_t)l * A.shadow_stride + h] = rec;
+                }
+            }
+        }
         A.next_keys[h] = RT_MISS_KEY;
         A.aux.nx[h] = nw.x; A.aux.ny[h] = nw.y; A.aux.nz[h] = nw.z;
         A.aux.vx[h] = rv.x; A.aux.vy[h] = rv.y; A.aux.vz[h] = rv.z;

@@ -227,4 +227,8 @@ def test_bounding_tests_on_larger_frames(family, seed, tmp_path):
         img, st = render(sc, **more)
         assert np.array_equal(img, want), (more, int((img != want).any(axis=-1).sum()))
         for key in ("rays_reflect", "rays_shadow", "hits", "in_plane_origin_hits"):
+            # (in-plane-origin hits are counted where listed pairs are re-tested: a ray whose pairs did not fit
+            # the pair list takes the full scan instead, which counts none -- comparable only without such rays)
+            if key == "in_plane_origin_hits" and (st["flagged_rays"] or sw["flagged_rays"]):
+                continue
             assert st[key] == sw[key], (key, more)

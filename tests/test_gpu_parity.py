@@ -31,9 +31,11 @@ def scene_file(name):
 
 
 def gpu_render(sc, exact_only=False, pass_pixels=None, tiles=None, filter_form=None, bvh=False, shared=None,
-               bounding=None):
+               bounding=None, scan_copies=None):
     from raytracer_amd.render import Renderer
     r = Renderer(sc)
+    if scan_copies is not None:
+        r.set_option(abi.RT_OPT_SCAN_COPIES, scan_copies)
     if shared is not None:
         r.set_option(abi.RT_OPT_SHARED_CONSTANTS, shared)
     if bounding is not None:
@@ -113,6 +115,24 @@ def test_shared_origin_and_direction_constants_change_nothing(name, w, h, depth)
         assert np.array_equal(a, b), form
         for k in ("rays_primary", "rays_reflect", "rays_shadow", "hits"):
             assert sa[k] == sb[k], (k, form)
+
+
+@pytest.mark.parametrize("name,w,h,depth", [("teapot", 1280, 720, 5), ("mixed_xf", 640, 480, 6), ("input-06", 512, 384, 6),
+                                           ("campanile_teddy", 480, 270, 3), ("synthetic_small", 480, 270, 4),
+                                           ("normals", 320, 240, 4), ("journal2", 320, 240, 6), ("scene1", 320, 240, 5),
+                                           ("s2", 320, 240, 5)])
+def test_scan_copies_change_nothing(name, w, h, depth):
+    """The kernels that make a ray also write the FP32 values the bounded scans hold for it (RT_OPT_SCAN_COPIES);
+    the scans load those instead of converting the ray's doubles.  The two must be the same bits: same frame,
+    same ray and hit counts, and the same pairs listed for the reference-precision re-test, in both forms of
+    the filter (scenes with identity and non-identity transforms, point and directional lights)."""
+    sc = Scene.load(scene_file(name), w, h, depth)
+    for form in (1, 2):
+        a, sa = gpu_render(sc, filter_form=form, scan_copies=1)
+        b, sb = gpu_render(sc, filter_form=form, scan_copies=0)
+        assert np.array_equal(a, b), form
+        for k in ("rays_primary", "rays_reflect", "rays_shadow", "hits", "exact_tests", "flagged_rays", "in_plane_origin_hits"):
+            assert sa[k] == sb[k], (k, form, sa[k], sb[k])
 
 
 @pytest.mark.parametrize("name,w,h,depth", [("teapot", 1280, 720, 5), ("mixed_xf", 640, 480, 6), ("input-06", 512, 384, 6),

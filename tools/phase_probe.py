@@ -39,6 +39,7 @@ for kind, v in st["scan_work"].items():
            "cycles_per_task": f[6] / f[0], "wave_life_cycles": life / max(1, f[8])}
     for i in range(1, 6):
         row[names[i] + "_share_of_tasks"] = round(f[i] / max(1, f[6]), 3)
+    row["ray_loop_share_of_tasks"] = round(f[9] / max(1, f[6]), 3)       # (part of the rays phase)
     row["tasks_share_of_life"] = round(f[6] / life, 3)
     out[kind] = row
 print(json.dumps(out, indent=1))
