@@ -237,6 +237,7 @@ struct rt_ctx {
     DevBuf<BvhNode> bvh_nodes;
     DevBuf<GroupBvh> bvh_groups;
     DevBuf<int> bvh_spill;                // deep traversal-stack entries, one strip per thread of the launch
+    DevBuf<unsigned long long> bvh_tally; // [2 kinds of query][aux_grid][4]: see BvhArgs::tally
     std::vector<Group> h_groups;
     std::vector<float> h_centroid_box;   // per group: min[3], max[3] of the triangle centroids
     double scene_bound = 0;
@@ -469,6 +470,7 @@ int launch_trace(rt_ctx* c, const Workspace& W, TraceArgs A, hipStream_t st, siz
             ba.exact = c->tri_exact.p; ba.groups = c->groups.p; ba.xforms = c->xforms.p;
             ba.spill = c->bvh_spill.p + (size_t)MODE * ((size_t)c->aux_grid * RT_BVH_BLOCK * RT_BVH_SPILL);   // one strip set per kind of query
             ba.counters = (BvhCounters*)&c->counters.p->bvh_node_tests;
+            ba.tally = c->bvh_tally.p + (size_t)MODE * (size_t)c->aux_grid * 4;
             hipLaunchKernelGGL(k_bvh_trace<MODE>, dim3(c->aux_grid), dim3(RT_BVH_BLOCK), 0, st, dsc, ba, A);
         } else {
             const dim3 block(RT_BLOCK);
@@ -564,6 +566,8 @@ int build_bvh(rt_ctx* c) {
     release_all();
     HIP_TRY(c->bvh_groups.upload(hb));
     HIP_TRY(c->bvh_spill.alloc(2 * (size_t)c->aux_grid * RT_BVH_BLOCK * RT_BVH_SPILL));
+    HIP_TRY(c->bvh_tally.alloc(2 * (size_t)c->aux_grid * 4));
+    HIP_TRY(hipMemset(c->bvh_tally.p, 0, 2 * (size_t)c->aux_grid * 4 * sizeof(unsigned long long)));
     c->bvh_built = true;
     return 0;
 }
@@ -1840,6 +1844,13 @@ int rt_get_stats(rt_ctx* c, rt_stats* out) {
     out->hits = dc.hits; out->closest_tests = dc.closest_tests; out->anyhit_tests = dc.anyhit_tests;
     out->exact_tests = dc.exact_tests;
     out->bvh_node_tests = dc.bvh_node_tests; out->bvh_leaf_tests = dc.bvh_leaf_tests;
+    if (c->bvh_tally.p) {       // the LBVH traversals count per block (BvhArgs::tally)
+        std::vector<unsigned long long> tally(2 * (size_t)c->aux_grid * 4);
+        HIP_TRY(hipMemcpy(tally.data(), c->bvh_tally.p, tally.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (size_t b = 0; b < tally.size(); b += 4) {
+            out->bvh_node_tests += tally[b]; out->bvh_leaf_tests += tally[b + 1]; out->exact_tests += tally[b + 2];
+        }
+    }
     out->in_plane_origin_hits = dc.in_plane_origin_hits; out->flagged_rays = dc.flagged_rays;
     out->closest_ms = c->ms[0] + c->ms[1] + c->ms[4]; out->anyhit_ms = c->ms[2] + c->ms[3] + c->ms[5];
     out->closest_launches = c->launches[0] + c->launches[1] + c->launches[4];
@@ -1863,6 +1874,7 @@ int rt_reset_stats(rt_ctx* c) {
     for (int k = 0; k <= RT_WORK_KINDS; k++) { c->ms[k] = 0; c->launches[k] = 0; }
     HIP_TRY(hipMemset(c->counters.p, 0, sizeof(DevCounters)));
     HIP_TRY(hipMemset(c->work.p, 0, RT_WORK_KINDS * RT_WORK_FIELDS * sizeof(unsigned long long)));
+    if (c->bvh_tally.p) HIP_TRY(hipMemset(c->bvh_tally.p, 0, 2 * (size_t)c->aux_grid * 4 * sizeof(unsigned long long)));
     return 0;
 }
 
@@ -1888,7 +1900,7 @@ void rt_free(rt_ctx* c) {
     for (auto e : c->ev_hit) (void)hipEventDestroy(e);
     for (auto e : c->ev_phong) (void)hipEventDestroy(e);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
-    c->bvh_nodes.release(); c->bvh_groups.release(); c->bvh_spill.release();
+    c->bvh_nodes.release(); c->bvh_groups.release(); c->bvh_spill.release(); c->bvh_tally.release();
     c->eye_a.release(); c->dir_rinv.release(); c->light_dir_row.release(); c->cone_camera.release();
     c->bound_lights.release(); c->light_frame.release(); c->sphere_any.release(); c->plane_any.release();
     c->cl_camera.release(); c->cl_lights.release(); c->cl_sphere.release(); c->cl_normal.release();

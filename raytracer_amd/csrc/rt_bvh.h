@@ -227,6 +227,10 @@ struct BvhArgs {
     const double* xforms;
     int* spill;                     // deep stack entries: [RT_BVH_SPILL][threads of the launch]
     BvhCounters* counters;
+    // Per block of the launch, 4 entries: box tests, leaf tests, reference-precision tests executed (and one
+    // spare), added up by the host when statistics are read.  (One set of counters for the whole launch had
+    // every wave end with three atomics on one 128-byte line: 24,000 per launch, one after the other.)
+    unsigned long long* tally;
 };
 
 template <int MODE>
@@ -380,9 +384,18 @@ k_bvh_trace(const DevScene* __restrict__ sc, BvhArgs B, TraceArgs A) {
     for (int off = 32; off > 0; off >>= 1) {
         n_node += __shfl_xor(n_node, off); n_leaf += __shfl_xor(n_leaf, off); n_exact += __shfl_xor(n_exact, off);
     }
+    // (every thread of the block gets here: the ray loop's trip count is the same for all of them)
+    __shared__ unsigned long long block_tally[3];
+    if (threadIdx.x < 3) block_tally[threadIdx.x] = 0ull;
+    __syncthreads();
     if (lane == 0) {
-        if (n_node) atomicAdd(&counters->node_tests, n_node);
-        if (n_leaf) atomicAdd(&counters->leaf_tests, n_leaf);
-        if (n_exact) atomicAdd(&A.counters->exact_tests, (unsigned long long)n_exact);
+        if (n_node) atomicAdd(&block_tally[0], n_node);
+        if (n_leaf) atomicAdd(&block_tally[1], n_leaf);
+        if (n_exact) atomicAdd(&block_tally[2], (unsigned long long)n_exact);
     }
+    __syncthreads();
+    // (launches of one kind of query follow each other on one stream, and each kind has its own tally: the
+    // block's entries are its own)
+    if (threadIdx.x < 3 && block_tally[threadIdx.x] != 0ull) B.tally[4 * (size_t)blockIdx.x + threadIdx.x] += block_tally[threadIdx.x];
+    (void)counters;
 }

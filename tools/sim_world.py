@@ -8,6 +8,9 @@ from raytracer_amd import Scene, abi
 from raytracer_amd.render import Renderer
 sc = Scene.load('scenes/teapot.scene', 3840, 2160, 5)
 r = Renderer(sc)
+import os
+if os.environ.get('RT_SCAN_COPIES'):
+    r.set_option(abi.RT_OPT_SCAN_COPIES, int(os.environ['RT_SCAN_COPIES']))
 frame = torch.zeros((2160, 3840, 4), dtype=torch.uint8, device='cuda')
 r.bind_frame(frame)
 st = torch.cuda.current_stream().cuda_stream
