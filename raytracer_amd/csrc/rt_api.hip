@@ -193,7 +193,7 @@ struct rt_ctx {
     DevBuf<DevCounters> counters;
     DevBuf<unsigned long long> work;   // [RT_WORK_KINDS][RT_WORK_FIELDS], see WorkCount
     int work_counters = 0;             // RT_OPT_WORK_COUNTERS
-    int scan_copies = 1;               // RT_OPT_SCAN_COPIES
+    int scan_copies = 0;               // RT_OPT_SCAN_COPIES (off: the scans gain 1-3 %, k_hit's extra stores cost the frame more)
     bool all_identity = false;         // every transform group is the identity (object space = world space)
 
     // workspace, sized for `ws.cap` rays per pass: one allocation, cut by carve_workspace
