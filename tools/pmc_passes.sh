@@ -3,7 +3,7 @@
 # (counters of one hardware block must fit that block's slots).
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/pmc_${TAG:-r2}
+OUT=gpurun_out/pmc_${TAG:-r2}      # (remove the local copy of this directory before merging a new run into it: the summary adds up every file it finds)
 rm -rf $OUT
 mkdir -p $OUT
 # two brute-force frames per pass: the timed one and the one of the kernel-timing leg
