@@ -820,6 +820,37 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
             return (PRE == 3) ? disc_reach(rec) : cone_reach(rec);
         }
     };
+    // PRE 4, one level up for the in-plane-origin question: can ANY member of cluster `cl` be named by some bundle?
+    // The members' unit normals lie within an angle alpha of the cluster's mean normal N (cl_normals: N, sin alpha),
+    // their planes pass through the cluster's sphere (C, rho).  For a bundle (centre m, ball radius R, cone axis a,
+    // half-angle beta, grazing bound) a member can only be named when
+    //   its plane can pass through the ball:  |n . (m - C)| - rho <= R, and |n . (m - C)| >= |m - C| cos(phi + alpha)
+    //     with phi the angle between m - C and +-N (while phi + alpha < 90 degrees), and
+    //   its plane can hold a grazing direction of the cone:  cos(theta + beta) <= bound with theta the angle between n
+    //     and +-a, and theta <= theta_N + alpha.
+    auto cluster_named = [&](const int cl) -> bool {
+        if (PRE != 4) return false;
+        const float4 sp = *(const float4*)(guard.cl_bounds + 4 * (size_t)cl);
+        const float4 nc = *(const float4*)(guard.cl_normals + 4 * (size_t)cl);
+        const float sa = nc.w, ca = judge_sqrt(fmaxf(1.0f - sa * sa, 0.0f));
+        bool named = false;
+#pragma unroll
+        for (int sb = 0; sb < (PRE == 4 ? RPL : 1); sb++) {
+            if (guard.qon[sb] < 0) continue;
+            if (guard.qon[sb] == 0) { named = true; continue; }
+            const float c1 = fabsf(nc.x * QB[sb].a[0] + nc.y * QB[sb].a[1] + nc.z * QB[sb].a[2]);
+            const float s1 = judge_sqrt(fmaxf(1.0f - c1 * c1, 0.0f));
+            const float cab = ca * QB[sb].a[3] - sa * QB[sb].a[4], sab = sa * QB[sb].a[3] + ca * QB[sb].a[4];   // cos, sin of alpha + beta
+            const bool can_graze = !(cab > 0.0f) | !(c1 * cab - s1 * sab > QB[sb].graze + 1e-4f);
+            const float dx = QB[sb].m[0] - sp.x, dy = QB[sb].m[1] - sp.y, dz = QB[sb].m[2] - sp.z;
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            const float along = fabsf(nc.x * dx + nc.y * dy + nc.z * dz);
+            const float least = along * ca - judge_sqrt(fmaxf(d2 - along * along, 0.0f)) * sa;                 // <= |n . (m - C)| for every member
+            const bool can_pass = !(least - sp.w > (QB[sb].m[4] + 2.0f * guard.slack) * (1.0f + 1e-4f) + 1e-5f * judge_sqrt(d2));
+            named |= can_graze & can_pass;
+        }
+        return named;
+    };
     for (cbeg = abeg; cbeg < aend; cbeg += CHUNK) {
         const int cend = min(cbeg + CHUNK, aend);
         n_cand = 0;
@@ -843,8 +874,9 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
             const unsigned long long cl_reach = __ballot(lane < n_grp && cluster_reach((cbeg >> 6) + lane));
             if (WORK) wk.v[RT_WK_CLUSTERS] += (unsigned int)n_grp;
             // ... then the triangles, one per lane, RT_GROUPS_AHEAD groups per round: of the clusters that
-            // passed, and (reflection rays) of the others for the in-plane-origin question alone
-            unsigned long long todo = (PRE == 4) ? ((n_grp >= 64) ? ~0ull : ((1ull << n_grp) - 1ull)) : cl_reach;
+            // passed, and (reflection rays) of those a member of which could be named, for that question alone
+            unsigned long long todo = cl_reach;
+            if (PRE == 4) todo |= __ballot(lane < n_grp && cluster_named((cbeg >> 6) + lane));
             while (todo != 0ull) {
                 int gi[RT_GROUPS_AHEAD];
                 float4 rec[RT_GROUPS_AHEAD], pl[RT_GROUPS_AHEAD];

@@ -131,7 +131,10 @@ def test_scan_copies_change_nothing(name, w, h, depth):
         a, sa = gpu_render(sc, filter_form=form, scan_copies=1)
         b, sb = gpu_render(sc, filter_form=form, scan_copies=0)
         assert np.array_equal(a, b), form
-        for k in ("rays_primary", "rays_reflect", "rays_shadow", "hits", "exact_tests", "flagged_rays", "in_plane_origin_hits"):
+        # (a pair list that runs full sends rays through the full scan instead; how many pairs were listed before
+        # that depends on the order in which the waves arrive: the listed pairs are comparable only without it)
+        full = sa["flagged_rays"] or sb["flagged_rays"]
+        for k in ("rays_primary", "rays_reflect", "rays_shadow", "hits") + (() if full else ("exact_tests", "in_plane_origin_hits")):
             assert sa[k] == sb[k], (k, form, sa[k], sb[k])
 
 
