@@ -35,7 +35,7 @@
 #define RT_RPL_SHARED 8         // ... in its instances for rays that share a point or a direction
 #endif
 #ifndef RT_GROUPS_AHEAD
-#define RT_GROUPS_AHEAD 4       // groups of 64 triangles whose bounding records a wave requests together
+#define RT_GROUPS_AHEAD 2       // groups of 64 triangles whose bounding records a wave requests together
 #endif
 #ifndef RT_RPL_ANY
 #define RT_RPL_ANY 4            // ... in its instance with a bounding test for rays with nothing in common (256 rays per
@@ -1229,7 +1229,7 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
     // (with the bounding tests a triangle costs a task a fraction of what loading its rays costs:
     // larger parts)
 #ifndef RT_MIN_PART_BOUNDED
-#define RT_MIN_PART_BOUNDED 512
+#define RT_MIN_PART_BOUNDED 256
 #endif
     int max_split = CONE ? (NR + RT_MIN_PART_BOUNDED - 1) / RT_MIN_PART_BOUNDED : (NR + 127) / 128;
     int split = 1;
