@@ -1291,8 +1291,9 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
 #endif
         unsigned int task = wave_id;
         if (!first_task) {
-            // (asked for here, not ahead of time: a ticket requested a task early returns in front of the task's ray
-            // loads in the wave's memory queue and was measured slower, 3.45 -> 3.62 ms on the reflection scan)
+            // (asked for here, not ahead of time: a wave that holds the number of its next task while it is still busy
+            // with a long one keeps that task from the waves that are idle -- the launch ends later.  Requested at
+            // the task's start, or behind the loads of the task's rays: both measured 5-9 % slower.)
             unsigned int t = 0;
             if (lane == 0) t = atomicAdd(A.task_counter, 1u);
             task = n_waves + (unsigned int)__builtin_amdgcn_readfirstlane(t);
