@@ -202,6 +202,7 @@ struct TraceArgs {
     uint32_t* occluded;                  // MODE 1: per hit, one bit per light
     int32_t occl_words;                  // MODE 1: 32-bit words per hit
     int32_t scan_all;                    // k_brute: 1 = test every triangle for every ray (filter switched off)
+    int32_t camera_rays;                 // MODE 0: 1 = the launch's rays are the pass's camera rays (origin = the eye)
     uint8_t* ray_flags;                  // per ray: 1 = k_brute must scan every triangle for it
     unsigned long long* pairs;           // (ray << 32) | exact-record slot
     // The pair list is cut into pair_lists (a power of two, at most RT_PAIR_LISTS) equal sub-lists of pair_seg
@@ -302,7 +303,8 @@ template <int MODE>
 __device__ __forceinline__ void load_world_ray(const TraceArgs& A, const DevScene* __restrict__ sc,
                                                unsigned int ray, unsigned int n_hits, d3* pos, d3* vec, int* source) {
     if (MODE == 0) {
-        *pos = mk3(A.rays.ox[ray], A.rays.oy[ray], A.rays.oz[ray]);
+        // (camera rays all start at the eye, which is what k_primary stored for each of them: not fetched)
+        *pos = A.camera_rays ? ld3(sc->cam_eye) : mk3(A.rays.ox[ray], A.rays.oy[ray], A.rays.oz[ray]);
         *vec = mk3(A.rays.dx[ray], A.rays.dy[ray], A.rays.dz[ray]);
         *source = -1;
     } else {
