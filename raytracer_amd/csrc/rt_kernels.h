@@ -1200,7 +1200,15 @@ __device__ __forceinline__ float uniform_f(float x) {      // a value every lane
 }
 
 template <int MODE, int RPL, bool ROBUST, int CONE, bool WORK = false>
-__global__ void __launch_bounds__(RT_BLOCK, RT_FILTER_MIN_WAVES)
+// (Four waves per SIMD for the camera and shadow instances -- 128 registers, 3 and 10 of them spilled to scratch --
+// made the shadow scan 3.5 % faster on its own and the frame no faster: the two streams already fill the idle slots.)
+#ifndef RT_MIN_WAVES_CAMERA
+#define RT_MIN_WAVES_CAMERA RT_FILTER_MIN_WAVES
+#endif
+#ifndef RT_MIN_WAVES_SHADOW
+#define RT_MIN_WAVES_SHADOW RT_FILTER_MIN_WAVES
+#endif
+__global__ void __launch_bounds__(RT_BLOCK, (CONE == 1 ? RT_MIN_WAVES_CAMERA : CONE == 2 ? RT_MIN_WAVES_SHADOW : RT_FILTER_MIN_WAVES))
 k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, TraceArgs A) {
     // The filter records are never written while a kernel runs: reading them through the
     // constant address space lets the compiler use scalar loads (s_load_dwordx16).
