@@ -93,7 +93,9 @@ typedef enum rt_option {
                                 frames as the scan EXCEPT for the in-plane-origin branch of Triangle::intersection
                                 (raytracer.cpp:319-321: a ray that starts exactly in a triangle's plane and grazes it
                                 "hits" at its own origin wherever the triangle is), which no box hierarchy can find;
-                                rt_stats.in_plane_origin_hits of a brute-force render says whether a scene has any */
+                                rt_stats.in_plane_origin_hits of a brute-force render says whether a scene has any.
+                                The traversal walks four-wide nodes (each binary node with its internal children
+                                replaced by theirs); 2: walk the binary tree itself (same frames, ~15 % slower) */
     RT_OPT_FILTER_FORM = 5,  /* form of the FP32 candidate filter: 0 = chosen from the scene when it was
                                 uploaded (default), 1 = static worst-case margins (cheapest test), 2 = per-test
                                 margins (one more instruction per test; for meshes of triangles that are

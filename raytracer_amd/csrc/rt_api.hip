@@ -235,6 +235,7 @@ struct rt_ctx {
     int use_bvh = 0;
     bool bvh_built = false;
     DevBuf<BvhNode> bvh_nodes;
+    DevBuf<BvhNode4> bvh_wide;            // the same nodes four-wide (what RT_OPT_USE_BVH = 1 traverses)
     DevBuf<GroupBvh> bvh_groups;
     DevBuf<int> bvh_spill;                // deep traversal-stack entries, one strip per thread of the launch
     DevBuf<unsigned long long> bvh_tally; // [2 kinds of query][aux_grid][4]: see BvhArgs::tally
@@ -467,12 +468,13 @@ int launch_trace(rt_ctx* c, const Workspace& W, TraceArgs A, hipStream_t st, siz
         Timed t(c, st, scan_kind, events);
         if (c->use_bvh) {
             BvhArgs ba;
-            ba.bvh = c->bvh_groups.p; ba.nodes = c->bvh_nodes.p; ba.filt = (const float*)c->tri_filt.p;
+            ba.bvh = c->bvh_groups.p; ba.nodes = c->bvh_nodes.p; ba.wide = c->bvh_wide.p; ba.filt = (const float*)c->tri_filt.p;
             ba.exact = c->tri_exact.p; ba.groups = c->groups.p; ba.xforms = c->xforms.p;
             ba.spill = c->bvh_spill.p + (size_t)MODE * ((size_t)c->aux_grid * RT_BVH_BLOCK * RT_BVH_SPILL);   // one strip set per kind of query
             ba.counters = (BvhCounters*)&c->counters.p->bvh_node_tests;
             ba.tally = c->bvh_tally.p + (size_t)MODE * (size_t)c->aux_grid * 4;
-            hipLaunchKernelGGL(k_bvh_trace<MODE>, dim3(c->aux_grid), dim3(RT_BVH_BLOCK), 0, st, dsc, ba, A);
+            if (c->use_bvh != 2) hipLaunchKernelGGL((k_bvh_trace<MODE, true>), dim3(c->aux_grid), dim3(RT_BVH_BLOCK), 0, st, dsc, ba, A);
+            else hipLaunchKernelGGL((k_bvh_trace<MODE, false>), dim3(c->aux_grid), dim3(RT_BVH_BLOCK), 0, st, dsc, ba, A);
         } else {
             const dim3 block(RT_BLOCK);
             const v16f* records = (const v16f*)c->tri_filt.p;
@@ -515,6 +517,7 @@ int build_bvh(rt_ctx* c) {
     const int NR = c->hs.n_regular;
     const size_t G = c->h_groups.size();
     HIP_TRY(c->bvh_nodes.alloc((size_t)std::max(NR, 1)));
+    HIP_TRY(c->bvh_wide.alloc((size_t)std::max(NR, 1)));
     std::vector<GroupBvh> hb(G);
     int max_n = 0;
     for (size_t g = 0; g < G; g++) max_n = std::max(max_n, c->h_groups[g].fax[3] - c->h_groups[g].fax[0]);
@@ -559,6 +562,8 @@ int build_bvh(rt_ctx* c) {
         hipLaunchKernelGGL(k_bvh_refit, dim3(blocks), dim3(256), 0, 0, (const TriExact*)c->tri_exact.p,
                            (const int*)vals_out.p, n, base, c->bvh_nodes.p + node_off, (const int*)parent_node.p,
                            (const int*)parent_leaf.p, arrive.p, pad_abs);
+        hipLaunchKernelGGL(k_bvh_widen, dim3(blocks), dim3(256), 0, 0, (const BvhNode*)(c->bvh_nodes.p + node_off), n - 1,
+                           c->bvh_wide.p + node_off);
         if (e == hipSuccess) e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(0);
         if (e != hipSuccess) { release_all(); return fail(RT_ERR_DEVICE, std::string("bvh build: ") + hipGetErrorString(e)); }
@@ -1601,7 +1606,7 @@ int rt_set_option(rt_ctx* c, int option, int64_t value) {
                 int rc = build_bvh(c);
                 if (rc) return rc;
             }
-            c->use_bvh = value ? 1 : 0;
+            c->use_bvh = value == 2 ? 2 : (value ? 1 : 0);      // 1: four-wide nodes, 2: the binary tree they are made from
             return 0;
         default: return fail(RT_ERR_ARG, "rt_set_option: unknown option");
     }
@@ -1901,7 +1906,7 @@ void rt_free(rt_ctx* c) {
     for (auto e : c->ev_hit) (void)hipEventDestroy(e);
     for (auto e : c->ev_phong) (void)hipEventDestroy(e);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
-    c->bvh_nodes.release(); c->bvh_groups.release(); c->bvh_spill.release(); c->bvh_tally.release();
+    c->bvh_nodes.release(); c->bvh_wide.release(); c->bvh_groups.release(); c->bvh_spill.release(); c->bvh_tally.release();
     c->eye_a.release(); c->dir_rinv.release(); c->light_dir_row.release(); c->cone_camera.release();
     c->bound_lights.release(); c->light_frame.release(); c->sphere_any.release(); c->plane_any.release();
     c->cl_camera.release(); c->cl_lights.release(); c->cl_sphere.release(); c->cl_normal.release();

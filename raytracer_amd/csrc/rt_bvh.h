@@ -153,6 +153,45 @@ __global__ void k_bvh_refit(const TriExact* __restrict__ exact, const int* __res
     }
 }
 
+// Four-wide nodes (what RT_OPT_USE_BVH = 1 traverses; 2 walks the binary tree): node i stands for binary node i with each internal child replaced by
+// that child's two children -- up to four boxes per step, half as many dependent node fetches per ray.  Every
+// binary node gets its wide form (one thread each, no compaction); a traversal that starts at the root only
+// ever visits those that stand for every second level.  Boxes and child codes are the binary tree's own.
+struct __attribute__((aligned(16))) BvhNode4 {
+    float lo[4][3], hi[4][3];
+    int32_t child[4];           // as BvhNode::child; RT_BVH_NO_CHILD: no such child
+    int32_t pad[4];
+};
+
+__global__ void k_bvh_widen(const BvhNode* __restrict__ nodes, int n_internal, BvhNode4* __restrict__ wide) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_internal) return;
+    BvhNode4 W;
+    int k = 0;
+    const BvhNode N = nodes[i];
+    for (int side = 0; side < 2; side++) {
+        const int c = N.child[side];
+        if (c == RT_BVH_NO_CHILD) continue;
+        if (c < 0 || c >= n_internal) {                         // a leaf (or a code this kernel does not follow): the child itself
+            for (int a = 0; a < 3; a++) { W.lo[k][a] = N.lo[side][a]; W.hi[k][a] = N.hi[side][a]; }
+            W.child[k++] = c;
+        } else {
+            const BvhNode M = nodes[c];
+            for (int s2 = 0; s2 < 2; s2++) {
+                if (M.child[s2] == RT_BVH_NO_CHILD) continue;
+                for (int a = 0; a < 3; a++) { W.lo[k][a] = M.lo[s2][a]; W.hi[k][a] = M.hi[s2][a]; }
+                W.child[k++] = M.child[s2];
+            }
+        }
+    }
+    for (; k < 4; k++) {
+        for (int a = 0; a < 3; a++) { W.lo[k][a] = 3.0e38f; W.hi[k][a] = -3.0e38f; }
+        W.child[k] = RT_BVH_NO_CHILD;
+    }
+    for (int q = 0; q < 4; q++) W.pad[q] = 0;
+    wide[i] = W;
+}
+
 // ---- traversal --------------------------------------------------------------
 
 struct BvhCounters { unsigned long long node_tests, leaf_tests; };
@@ -221,6 +260,7 @@ __device__ __forceinline__ bool ray_reaches_box(const float* lo, const float* hi
 struct BvhArgs {
     const GroupBvh* bvh;            // per group
     const BvhNode* nodes;           // all groups' nodes; GroupBvh::node_offset indexes into it
+    const BvhNode4* wide;           // the same nodes four-wide (WIDE instances)
     const float* filt;              // FP32 filter records, 16 floats per regular triangle
     const TriExact* exact;
     const Group* groups;
@@ -233,7 +273,7 @@ struct BvhArgs {
     unsigned long long* tally;
 };
 
-template <int MODE>
+template <int MODE, bool WIDE = false>
 __global__ void __launch_bounds__(RT_BVH_BLOCK)
 k_bvh_trace(const DevScene* __restrict__ sc, BvhArgs B, TraceArgs A) {
     const GroupBvh* __restrict__ bvh = B.bvh;
@@ -284,6 +324,8 @@ k_bvh_trace(const DevScene* __restrict__ sc, BvhArgs B, TraceArgs A) {
         float px = 0, py = 0, pz = 0, vx = 0, vy = 0, vz = 1, ix = 0, iy = 0, iz = 1, t_limit = INFINITY;
         const Group* G = B.groups;
         const BvhNode* nodes = nullptr;
+        const BvhNode4* wide = nullptr;
+        int n_internal = 0;
         bool prune = false;
 
         while (__any(active)) {
@@ -310,6 +352,7 @@ k_bvh_trace(const DevScene* __restrict__ sc, BvhArgs B, TraceArgs A) {
                     ix = 1.0f / vx; iy = 1.0f / vy; iz = 1.0f / vz;
                     t_limit = prune ? t_limit_identity : INFINITY;
                     nodes = B.nodes + bvh[g].node_offset;
+                    if (WIDE) { wide = B.wide + bvh[g].node_offset; n_internal = n - 1; }
                     cur = (n == 1) ? (-1 - bvh[g].first_slot) : 0;
                     sp = 0;
                     need_group = false;
@@ -329,6 +372,40 @@ k_bvh_trace(const DevScene* __restrict__ sc, BvhArgs B, TraceArgs A) {
                     }
                     if (sp == 0) need_group = true;
                     else cur = stack_get(--sp);
+                    continue;
+                }
+                if (WIDE) {
+                    // (a child code outside the group's nodes cannot come from a sound tree: the ray takes the full scan)
+                    if (cur >= n_internal) { bail = true; active = false; break; }
+                    const BvhNode4& N4 = wide[cur];
+                    float d[4];
+                    int c[4];
+                    int n_hit = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        float tn;
+                        const bool r = ray_reaches_box(N4.lo[k], N4.hi[k], px, py, pz, ix, iy, iz, &tn);
+                        c[k] = N4.child[k];
+                        const bool h = r & !(tn > t_limit) & (c[k] != RT_BVH_NO_CHILD);
+                        d[k] = h ? tn : INFINITY;
+                        n_hit += h ? 1 : 0;
+                        n_node += (c[k] != RT_BVH_NO_CHILD) ? 1 : 0;
+                    }
+                    // nearest first: a five-exchange sorting network on (entry parameter, child); boxes not reached sort last
+#define RT_BVH_CSWAP(i, j) { const bool sw = d[j] < d[i]; const float td = sw ? d[j] : d[i]; d[j] = sw ? d[i] : d[j]; d[i] = td; \
+                             const int tc = sw ? c[j] : c[i]; c[j] = sw ? c[i] : c[j]; c[i] = tc; }
+                    RT_BVH_CSWAP(0, 1) RT_BVH_CSWAP(2, 3) RT_BVH_CSWAP(0, 2) RT_BVH_CSWAP(1, 3) RT_BVH_CSWAP(1, 2)
+#undef RT_BVH_CSWAP
+                    if (n_hit == 0) {
+                        if (sp == 0) need_group = true;
+                        else cur = stack_get(--sp);
+                    } else {
+                        if (sp + 3 > RT_BVH_STACK + RT_BVH_SPILL) { bail = true; active = false; break; }
+                        if (n_hit > 3) stack_put(sp++, c[3]);
+                        if (n_hit > 2) stack_put(sp++, c[2]);
+                        if (n_hit > 1) stack_put(sp++, c[1]);
+                        cur = c[0];
+                    }
                     continue;
                 }
                 const BvhNode& N = nodes[cur];

@@ -23,7 +23,7 @@ def render(sc, bvh):
     from raytracer_amd.render import Renderer
     r = Renderer(sc)
     if bvh:
-        r.set_option(abi.RT_OPT_USE_BVH, 1)
+        r.set_option(abi.RT_OPT_USE_BVH, int(bvh))      # 1: four-wide nodes, 2: the binary tree
     r.render_frame()
     img, st = r.download(), r.stats()
     r.close()
@@ -38,20 +38,23 @@ def render(sc, bvh):
 def test_bvh_frame_equals_brute_force(name, w, h, depth):
     sc = Scene.load(os.path.join(ROOT, "scenes", name), w, h, depth)
     a, sa = render(sc, bvh=False)
-    b, sb = render(sc, bvh=True)
     assert sa["in_plane_origin_hits"] == 0
-    assert np.array_equal(a, b), int((a != b).any(axis=-1).sum())
-    for k in ("rays_primary", "rays_reflect", "rays_shadow", "hits"):
-        assert sa[k] == sb[k], k
-    if sa["n_triangles"] - sa["n_irregular"] > 1:
-        assert sb["bvh_node_tests"] > 0 and sb["bvh_leaf_tests"] > 0
+    for mode in (1, 2):
+        b, sb = render(sc, bvh=mode)
+        assert np.array_equal(a, b), (mode, int((a != b).any(axis=-1).sum()))
+        for k in ("rays_primary", "rays_reflect", "rays_shadow", "hits"):
+            assert sa[k] == sb[k], (k, mode)
+        assert sb["flagged_rays"] == 0, mode          # (no ray fell back to the full scan)
+        if sa["n_triangles"] - sa["n_irregular"] > 1:
+            assert sb["bvh_node_tests"] > 0 and sb["bvh_leaf_tests"] > 0
 
 
 def test_bvh_teapot_4k_equals_brute_force():
     sc = Scene.load(os.path.join(ROOT, "scenes", "teapot.scene"), 3840, 2160, 5)
     a, sa = render(sc, bvh=False)
-    b, sb = render(sc, bvh=True)
-    assert np.array_equal(a, b)
-    assert sa["hits"] == sb["hits"] and sa["rays_shadow"] == sb["rays_shadow"]
-    # the hierarchy must prune: far fewer leaf tests than the brute-force pair count
-    assert sb["bvh_leaf_tests"] * 20 < sa["closest_tests"] + sa["anyhit_tests"]
+    for mode in (1, 2):
+        b, sb = render(sc, bvh=mode)
+        assert np.array_equal(a, b), mode
+        assert sa["hits"] == sb["hits"] and sa["rays_shadow"] == sb["rays_shadow"]
+        # the hierarchy must prune: far fewer leaf tests than the brute-force pair count
+        assert sb["bvh_leaf_tests"] * 20 < sa["closest_tests"] + sa["anyhit_tests"]

@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 from raytracer_amd import Scene, abi
 from raytracer_amd.render import Renderer
 r = Renderer(Scene.load(os.path.join(ROOT, "scenes", "teapot.scene"), 3840, 2160, 5))
-r.set_option(abi.RT_OPT_USE_BVH, 1)
+r.set_option(abi.RT_OPT_USE_BVH, int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 for _ in range(3):
     r.render_frame()
 r.stats()
