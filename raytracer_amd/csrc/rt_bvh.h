@@ -19,10 +19,16 @@
 #include "rt_kernels.h"
 
 #define RT_BVH_BLOCK 256
+#ifndef RT_BVH_STACK
 #define RT_BVH_STACK 24         // per-lane traversal stack entries kept in LDS
+#endif
 #define RT_BVH_SPILL 48         // ... and deeper ones in a per-thread strip of global memory
+#ifndef RT_BVH_STAGE
 #define RT_BVH_STAGE 4          // per-lane staged candidates (LDS)
+#endif
+#ifndef RT_BVH_STEPS
 #define RT_BVH_STEPS 8          // traversal steps between two drain phases
+#endif
 #define RT_BVH_NO_CHILD (-2147483647 - 1)   // child code of a leaf whose slot holds no triangle (TriExact::hole): never entered
 
 struct __attribute__((aligned(16))) BvhNode {
