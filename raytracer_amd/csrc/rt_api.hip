@@ -522,11 +522,14 @@ int build_bvh(rt_ctx* c) {
     int max_n = 0;
     for (size_t g = 0; g < G; g++) max_n = std::max(max_n, c->h_groups[g].fax[3] - c->h_groups[g].fax[0]);
     DevBuf<unsigned int> keys_in, keys_out, arrive;
-    DevBuf<int> vals_in, vals_out, parent_node, parent_leaf;
+    DevBuf<int> vals_in, vals_out, parent_node, parent_leaf, leaf_of_slot;
     DevBuf<char> temp;
+    // passes of tree rotations over the finished binary tree (k_bvh_rotate); RAYTRACER_AMD_BVH_ROTATIONS overrides
+    int rotation_passes = RT_BVH_ROTATION_PASSES;
+    if (const char* env = std::getenv("RAYTRACER_AMD_BVH_ROTATIONS")) rotation_passes = std::max(0, std::min(16, std::atoi(env)));
     const size_t m = (size_t)std::max(max_n, 1);
     HIP_TRY(keys_in.alloc(m)); HIP_TRY(keys_out.alloc(m)); HIP_TRY(vals_in.alloc(m)); HIP_TRY(vals_out.alloc(m));
-    HIP_TRY(parent_node.alloc(m)); HIP_TRY(parent_leaf.alloc(m)); HIP_TRY(arrive.alloc(m));
+    HIP_TRY(parent_node.alloc(m)); HIP_TRY(parent_leaf.alloc(m)); HIP_TRY(arrive.alloc(m)); HIP_TRY(leaf_of_slot.alloc(m));
     size_t temp_bytes = 0;
     HIP_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, keys_in.p, keys_out.p, vals_in.p, vals_out.p, m, 0, 30));
     HIP_TRY(temp.alloc(std::max<size_t>(temp_bytes, 16)));
@@ -534,7 +537,7 @@ int build_bvh(rt_ctx* c) {
     size_t node_off = 0;
     auto release_all = [&]() {
         keys_in.release(); keys_out.release(); vals_in.release(); vals_out.release();
-        parent_node.release(); parent_leaf.release(); arrive.release(); temp.release();
+        parent_node.release(); parent_leaf.release(); arrive.release(); temp.release(); leaf_of_slot.release();
     };
     for (size_t g = 0; g < G; g++) {
         const Group& Gr = c->h_groups[g];
@@ -562,6 +565,16 @@ int build_bvh(rt_ctx* c) {
         hipLaunchKernelGGL(k_bvh_refit, dim3(blocks), dim3(256), 0, 0, (const TriExact*)c->tri_exact.p,
                            (const int*)vals_out.p, n, base, c->bvh_nodes.p + node_off, (const int*)parent_node.p,
                            (const int*)parent_leaf.p, arrive.p, pad_abs);
+        if (rotation_passes > 0 && n > 2) {
+            hipLaunchKernelGGL(k_bvh_leaf_of_slot, dim3(blocks), dim3(256), 0, 0, n, (const int*)vals_out.p, leaf_of_slot.p);
+            for (int pass = 0; pass < rotation_passes && e == hipSuccess; pass++) {
+                e = hipMemsetAsync(arrive.p, 0, (size_t)n * sizeof(unsigned int), 0);
+                hipLaunchKernelGGL(k_bvh_rotate, dim3(blocks), dim3(256), 0, 0, n, c->bvh_nodes.p + node_off,
+                                   (const int*)parent_node.p, (const int*)parent_leaf.p, arrive.p, (unsigned int*)nullptr);
+                hipLaunchKernelGGL(k_bvh_links, dim3(blocks), dim3(256), 0, 0, n, base, (const BvhNode*)(c->bvh_nodes.p + node_off),
+                                   (const int*)leaf_of_slot.p, parent_node.p, parent_leaf.p);
+            }
+        }
         hipLaunchKernelGGL(k_bvh_widen, dim3(blocks), dim3(256), 0, 0, (const BvhNode*)(c->bvh_nodes.p + node_off), n - 1,
                            c->bvh_wide.p + node_off);
         if (e == hipSuccess) e = hipGetLastError();
