@@ -117,12 +117,22 @@ typedef enum rt_option {
     RT_OPT_WORK_COUNTERS = 9, /* 1: the brute-force scans count the work they execute (rt_stats.scan_work) in
                                  instances of the scan kernels compiled for it; 0 (default): the scans carry no
                                  counting code.  Frames are identical */
-    RT_OPT_SCAN_COPIES = 10   /* 1: the kernels that make a ray also write the FP32 values the bounded scans hold
+    RT_OPT_SCAN_COPIES = 10,  /* 1: the kernels that make a ray also write the FP32 values the bounded scans hold
                                  for it (36 bytes per ray, 16 per shadow ray for up to 8 lights), and the scans
                                  load those instead of converting the ray's doubles again for every part of the
                                  triangle range; 0 (default): the scans convert.  Same bits either way: frames,
                                  pair lists and counters are identical.  Measured on the 4K teapot frame: the
                                  scans 1-3 % faster, the frame 1.5-2.5 % slower (the extra stores) -- hence off */
+    RT_OPT_FRAMES_IN_FLIGHT = 11 /* 1 (default): a render call's work runs on the caller's stream (and the internal
+                                 stream of RT_OPT_OVERLAP, joined back before the call's last kernel).  2..4: that
+                                 many render calls may be in flight at once: call i runs on internal streams of its
+                                 own with workspace i mod N, behind the work that was on the caller's stream at the
+                                 time of the call, and is NOT joined back -- rt_join does that.  The short launches
+                                 at the deep levels of one frame then run beside the large launches of the next
+                                 (4K teapot frame: 6.2 -> 5.5 ms per frame at 3; one rank's eighth of it: 1.96 ->
+                                 1.5 ms).  Pixels are identical; calls that write the same pixels land in call
+                                 order.  N workspaces are held.  RT_OPT_PROFILE and RT_OPT_WORK_COUNTERS renders
+                                 run as with 1.  Blocks until queued work has finished */
 } rt_option;
 
 /* Executed work of the brute-force scans of one kind of ray (RT_OPT_WORK_COUNTERS).  A scan hands
@@ -200,6 +210,16 @@ int rt_render_tile(rt_ctx* ctx, int y0, int rows, void* stream);
  * tile k is film rows [k*tile_rows, min((k+1)*tile_rows, height)); one rank of
  * an N-GPU job calls it with first_tile = rank, tile_step = N. */
 int rt_render_tiles(rt_ctx* ctx, int first_tile, int tile_rows, int tile_step, void* stream);
+
+/* With RT_OPT_FRAMES_IN_FLIGHT > 1 (a no-op otherwise): makes `stream` wait -- on the device, the
+ * call does not block the host -- for every render call of this ctx issued so far except the
+ * `keep_latest` most recent ones (0: all of them).  What is enqueued on `stream` afterwards sees
+ * those calls' pixels; a caller that pipelines frames binds one frame buffer per call in flight
+ * (rt_bind_frame takes effect for the calls after it) and hands frame i on while frame i+1 is
+ * traced.  rt_download, rt_get_stats, rt_reset_stats and rt_free wait for everything by
+ * themselves.  No counterpart in the reference, whose render() returns when the film is full
+ * (raytracer.cpp:497-511). */
+int rt_join(rt_ctx* ctx, void* stream, int keep_latest);
 
 /* rt_render_tile for callers that cannot allocate device memory at the time of the call (code
  * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the same

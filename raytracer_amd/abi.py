@@ -14,6 +14,7 @@ RT_OPT_EXACT_ONLY, RT_OPT_PROFILE, RT_OPT_PASS_PIXELS, RT_OPT_USE_BVH, RT_OPT_FI
 RT_OPT_BOUNDING_TESTS = 8
 RT_OPT_WORK_COUNTERS = 9
 RT_OPT_SCAN_COPIES = 10
+RT_OPT_FRAMES_IN_FLIGHT = 11
 SCAN_KINDS = ["plain_nearest", "camera", "shadow_point", "shadow_directional", "reflection", "plain_shadow"]
 
 
@@ -78,7 +79,7 @@ class RtStats(C.Structure):
 
 HOST_SYMBOLS = ["rth_load_scene", "rth_load_blob", "rth_save_blob", "rth_desc", "rth_free_scene",
                 "rth_write_png", "rth_tile_span", "rth_last_error"]
-DEVICE_SYMBOLS = ["rt_upload_scene", "rt_set_option", "rt_render_tile", "rt_render_tiles", "rt_render_tile_noalloc",
+DEVICE_SYMBOLS = ["rt_upload_scene", "rt_set_option", "rt_render_tile", "rt_render_tiles", "rt_join", "rt_render_tile_noalloc",
                   "rt_bind_frame", "rt_download", "rt_primary_hits", "rt_bounce_probe", "rt_queue_pixel", "rt_get_stats", "rt_reset_stats", "rt_device_info",
                   "rt_free", "rt_last_error"]
 
@@ -138,6 +139,8 @@ def device_lib():
         lib.rt_render_tile_noalloc.restype = C.c_int
         lib.rt_render_tiles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         lib.rt_render_tiles.restype = C.c_int
+        lib.rt_join.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        lib.rt_join.restype = C.c_int
         lib.rt_bind_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         lib.rt_bind_frame.restype = C.c_int
         lib.rt_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]

@@ -173,6 +173,20 @@ struct Workspace {
     float4* shadow_scan[2] = {nullptr, nullptr};       // [n_lights][cap], by level parity
 };
 
+// What one render call in flight owns (RT_OPT_FRAMES_IN_FLIGHT > 1): a workspace, the two streams of a pass,
+// the per-level events between them, the LBVH traversal's per-thread strips and per-block tallies.
+struct Lane {
+    Workspace ws;
+    DevBuf<unsigned char> block;
+    hipStream_t main = nullptr, side = nullptr;
+    std::vector<hipEvent_t> ev_hit, ev_phong;
+    hipEvent_t in = nullptr, done = nullptr;   // the caller's stream at the time of the call / the call's last kernel
+    bool pending = false;                      // `done` was recorded and nobody has waited for all of it yet
+    unsigned long long seq = 0;                // number of the render call that recorded `done`
+    DevBuf<int> bvh_spill;
+    DevBuf<unsigned long long> bvh_tally;
+};
+
 struct rt_ctx {
     int device = 0;
     int n_cu = 0;
@@ -202,6 +216,12 @@ struct rt_ctx {
     hipStream_t side_stream = nullptr;    // the shadow/Phong half of a level runs here
     std::vector<hipEvent_t> ev_hit, ev_phong;   // per level: k_hit done / k_phong done
     int overlap = 1;                      // RT_OPT_OVERLAP
+    // RT_OPT_FRAMES_IN_FLIGHT: render call i runs in lanes[i % in_flight] (none of this is used at 1)
+    int in_flight = 1;
+    std::vector<Lane*> lanes;
+    Lane* cur = nullptr;                  // the lane of the call being enqueued (null: the context's own resources)
+    hipEvent_t prev_done = nullptr;       // `done` of the previous call in flight: the folds keep call order
+    unsigned long long seq = 0;           // render calls issued in lanes so far
 
     // host copies kept so that the filter form can be switched after the upload
     std::vector<HostTri> h_tris;          // in Scene::objects order (triangles only)
@@ -340,7 +360,8 @@ size_t carve_workspace(Workspace* w, unsigned char* base, size_t cap, int levels
 // Sizes the context's own workspace for the current options.  Nothing in the context changes
 // unless every step succeeds: a failure leaves the previous workspace (or none) in place and
 // the caller returns the error without launching anything.
-int ensure_workspace(rt_ctx* c) {
+// Pixels per pass for the current options (whole rows), and the error if even one row is too many.
+int pass_size(const rt_ctx* c, size_t* want_out) {
     size_t frame_px = (size_t)c->hs.width * c->hs.height;
     // shadow rays of a pass are numbered with 31 bits
     const long long by_lights = ((1ll << 31) - 1) / std::max(1, c->hs.n_lights);
@@ -348,11 +369,19 @@ int ensure_workspace(rt_ctx* c) {
     size_t want = (size_t)std::min<long long>((long long)frame_px, budget);
     // whole rows per pass
     want = std::max<size_t>(c->hs.width, want / c->hs.width * c->hs.width);
-    int levels = c->hs.max_depth + 1;
-    if (c->ws.cap == want && c->ws.levels == levels && c->ws_block.p) return 0;
     const size_t shadow_rays = want * (size_t)std::max(1, c->hs.n_lights);
     if (shadow_rays >= (1ull << 31))
         return fail(RT_ERR_RANGE, "pass too large (one row of shadow rays exceeds 2^31): fewer lights or a narrower frame");
+    *want_out = want;
+    return 0;
+}
+
+int ensure_workspace(rt_ctx* c) {
+    size_t want = 0;
+    int rc = pass_size(c, &want);
+    if (rc) return rc;
+    const int levels = c->hs.max_depth + 1;
+    if (c->ws.cap == want && c->ws.levels == levels && c->ws_block.p) return 0;
     if (!c->side_stream) HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
     while ((int)c->ev_hit.size() < levels || (int)c->ev_phong.size() < levels) {
         hipEvent_t e = nullptr;
@@ -405,6 +434,82 @@ void drain_spans(rt_ctx* c) {
         c->event_pool.push_back(s.b);
     }
     c->spans.clear();
+}
+
+// ---- RT_OPT_FRAMES_IN_FLIGHT > 1 ---------------------------------------------------------------------------
+void release_lane(Lane* L) {
+    if (!L) return;
+    for (auto e : L->ev_hit) (void)hipEventDestroy(e);
+    for (auto e : L->ev_phong) (void)hipEventDestroy(e);
+    if (L->in) (void)hipEventDestroy(L->in);
+    if (L->done) (void)hipEventDestroy(L->done);
+    if (L->main) (void)hipStreamDestroy(L->main);
+    if (L->side) (void)hipStreamDestroy(L->side);
+    delete L;             // (the buffers release themselves)
+}
+
+// Host-side wait for everything the context has enqueued: the last caller's stream and every lane.
+int sync_all(rt_ctx* c) {
+    HIP_TRY(hipStreamSynchronize(c->last_stream));
+    for (Lane* L : c->lanes) {
+        if (!L->pending) continue;
+        HIP_TRY(hipStreamSynchronize(L->main));      // (the side stream was joined into it before the folds)
+        L->pending = false;
+    }
+    c->prev_done = nullptr;
+    return 0;
+}
+
+void drop_lanes(rt_ctx* c) {
+    for (Lane* L : c->lanes) release_lane(L);
+    c->lanes.clear();
+    c->prev_done = nullptr;
+    c->cur = nullptr;
+}
+
+// `in_flight` lanes, each with a workspace for the current options, streams, events and (when the LBVH is built)
+// traversal strips.  A lane is only added to the context when all of it exists.
+int ensure_lanes(rt_ctx* c) {
+    size_t want = 0;
+    int rc = pass_size(c, &want);
+    if (rc) return rc;
+    const int levels = c->hs.max_depth + 1;
+    bool stale = (int)c->lanes.size() > c->in_flight;
+    for (Lane* L : c->lanes) stale = stale || L->ws.cap != want || L->ws.levels != levels;
+    if (stale) {
+        HIP_TRY(hipDeviceSynchronize());
+        drop_lanes(c);
+    }
+    while ((int)c->lanes.size() < c->in_flight) {
+        Lane* L = new Lane;
+        auto give_up = [&](int code, const std::string& msg) { release_lane(L); return fail(code, msg); };
+        hipError_t e = hipStreamCreateWithFlags(&L->main, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&L->side, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&L->in, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&L->done, hipEventDisableTiming);
+        for (int k = 0; k < 2 * levels && e == hipSuccess; k++) {
+            hipEvent_t ev = nullptr;
+            e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e == hipSuccess) ((k & 1) ? L->ev_phong : L->ev_hit).push_back(ev);
+        }
+        if (e != hipSuccess) return give_up(RT_ERR_DEVICE, std::string("frames in flight: ") + hipGetErrorString(e));
+        const size_t bytes = carve_workspace(nullptr, nullptr, want, levels, c->hs.n_lights, c->aux_grid, 16, (size_t)1 << 20, true);
+        e = L->block.alloc(bytes);
+        if (e != hipSuccess)
+            return give_up(RT_ERR_DEVICE, std::string("workspace of ") + std::to_string(bytes >> 20) + " MiB for a frame in flight: " +
+                                              hipGetErrorString(e) + " (lower RT_OPT_PASS_PIXELS or RT_OPT_FRAMES_IN_FLIGHT)");
+        carve_workspace(&L->ws, L->block.p, want, levels, c->hs.n_lights, c->aux_grid, 16, (size_t)1 << 20, true);
+        e = hipMemset(L->ws.hit_offsets, 0, ((size_t)c->aux_grid + 1) * sizeof(uint32_t));
+        if (e != hipSuccess) return give_up(RT_ERR_DEVICE, std::string("frames in flight: ") + hipGetErrorString(e));
+        c->lanes.push_back(L);
+    }
+    for (Lane* L : c->lanes) {
+        if (!c->bvh_built || L->bvh_spill.p) continue;
+        HIP_TRY(L->bvh_spill.alloc(2 * (size_t)c->aux_grid * RT_BVH_BLOCK * RT_BVH_SPILL));
+        HIP_TRY(L->bvh_tally.alloc(2 * (size_t)c->aux_grid * 4));
+        HIP_TRY(hipMemset(L->bvh_tally.p, 0, 2 * (size_t)c->aux_grid * 4 * sizeof(unsigned long long)));
+    }
+    return 0;
 }
 
 struct Timed {
@@ -470,9 +575,11 @@ int launch_trace(rt_ctx* c, const Workspace& W, TraceArgs A, hipStream_t st, siz
             BvhArgs ba;
             ba.bvh = c->bvh_groups.p; ba.nodes = c->bvh_nodes.p; ba.wide = c->bvh_wide.p; ba.filt = (const float*)c->tri_filt.p;
             ba.exact = c->tri_exact.p; ba.groups = c->groups.p; ba.xforms = c->xforms.p;
-            ba.spill = c->bvh_spill.p + (size_t)MODE * ((size_t)c->aux_grid * RT_BVH_BLOCK * RT_BVH_SPILL);   // one strip set per kind of query
+            int* spill = c->cur ? c->cur->bvh_spill.p : c->bvh_spill.p;
+            unsigned long long* tally = c->cur ? c->cur->bvh_tally.p : c->bvh_tally.p;
+            ba.spill = spill + (size_t)MODE * ((size_t)c->aux_grid * RT_BVH_BLOCK * RT_BVH_SPILL);   // one strip set per kind of query
             ba.counters = (BvhCounters*)&c->counters.p->bvh_node_tests;
-            ba.tally = c->bvh_tally.p + (size_t)MODE * (size_t)c->aux_grid * 4;
+            ba.tally = tally + (size_t)MODE * (size_t)c->aux_grid * 4;
             if (c->use_bvh != 2) hipLaunchKernelGGL((k_bvh_trace<MODE, true>), dim3(c->aux_grid), dim3(RT_BVH_BLOCK), 0, st, dsc, ba, A);
             else hipLaunchKernelGGL((k_bvh_trace<MODE, false>), dim3(c->aux_grid), dim3(RT_BVH_BLOCK), 0, st, dsc, ba, A);
         } else {
@@ -623,7 +730,10 @@ int run_pass(rt_ctx* c, const Workspace& ws, PassDesc pd, int nrows, hipStream_t
     // its own.  Hit auxiliaries and occlusion bits alternate between two buffers by level
     // parity; k_hit of level k+2 waits for k_phong of level k before it overwrites them.
     const bool overlap = side_work && c->overlap && !c->profile && levels > 1;
-    hipStream_t sb = overlap ? c->side_stream : st;
+    hipStream_t side = c->cur ? c->cur->side : c->side_stream;
+    hipEvent_t* ev_hit = c->cur ? c->cur->ev_hit.data() : c->ev_hit.data();
+    hipEvent_t* ev_phong = c->cur ? c->cur->ev_phong.data() : c->ev_phong.data();
+    hipStream_t sb = overlap ? side : st;
     for (int k = 0; k < levels; k++) {
         const int cur = k & 1, nxt = cur ^ 1;
         LevelStore lvl = level_of(ws, k);
@@ -639,7 +749,7 @@ int run_pass(rt_ctx* c, const Workspace& ws, PassDesc pd, int nrows, hipStream_t
         int rc = launch_trace<0>(c, ws, ta, st, (size_t)n_pix, k == 0, side_work);
         if (rc) return rc;
 
-        if (overlap && k >= 2) HIP_TRY(hipStreamWaitEvent(st, c->ev_phong[k - 2], 0));
+        if (overlap && k >= 2) HIP_TRY(hipStreamWaitEvent(st, ev_phong[k - 2], 0));
         HitArgs ha{};
         ha.sc = dsc; ha.cur = q[cur]; ha.next = q[nxt]; ha.keys = ws.keys[cur]; ha.next_keys = ws.keys[nxt];
         ha.n_rays = ws.counts + k; ha.hit_offsets = ws.hit_offsets; ha.lvl = lvl; ha.aux = aux;
@@ -651,8 +761,8 @@ int run_pass(rt_ctx* c, const Workspace& ws, PassDesc pd, int nrows, hipStream_t
         hipLaunchKernelGGL(k_hit, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, ha);
         HIP_TRY(hipGetLastError());
         if (overlap) {
-            HIP_TRY(hipEventRecord(c->ev_hit[k], st));
-            HIP_TRY(hipStreamWaitEvent(sb, c->ev_hit[k], 0));
+            HIP_TRY(hipEventRecord(ev_hit[k], st));
+            HIP_TRY(hipStreamWaitEvent(sb, ev_hit[k], 0));
         }
 
         if (c->hs.n_lights > 0) {
@@ -669,10 +779,12 @@ int run_pass(rt_ctx* c, const Workspace& ws, PassDesc pd, int nrows, hipStream_t
         pa.occl_words = ws.occl_words; pa.cap = (uint32_t)ws.cap; pa.n_hits = ws.counts + k + 1;
         hipLaunchKernelGGL(k_phong, dim3(c->aux_grid), dim3(RT_BLOCK), 0, sb, pa);
         HIP_TRY(hipGetLastError());
-        if (overlap) HIP_TRY(hipEventRecord(c->ev_phong[k], sb));
+        if (overlap) HIP_TRY(hipEventRecord(ev_phong[k], sb));
     }
     // the fold (and whatever the caller enqueues next) comes after everything on the side stream
-    if (overlap) HIP_TRY(hipStreamWaitEvent(st, c->ev_phong[levels - 1], 0));
+    if (overlap) HIP_TRY(hipStreamWaitEvent(st, ev_phong[levels - 1], 0));
+    // ... and, with several calls in flight, after the folds of the call before this one: pixels land in call order
+    if (c->cur && c->prev_done) HIP_TRY(hipStreamWaitEvent(st, c->prev_done, 0));
     for (int k = levels - 1; k >= 0; k--) {
         FoldArgs fa{};
         fa.sc = dsc; fa.lvl = level_of(ws, k); fa.parent_lvl = level_of(ws, k > 0 ? k - 1 : 0);
@@ -689,8 +801,6 @@ int run_pass(rt_ctx* c, const Workspace& ws, PassDesc pd, int nrows, hipStream_t
 // Rows y_start + j*stride_rows + [0, tile_rows) for j = 0 .. n_tiles-1 (clipped to the frame).
 int render_rows(rt_ctx* c, int y_start, int tile_rows, int stride_rows, int n_tiles, hipStream_t st) {
     HIP_TRY(hipSetDevice(c->device));
-    int rc = ensure_workspace(c);
-    if (rc) return rc;
     const int H = c->hs.height, W = c->hs.width;
     // valid rows form a prefix of the pass's row sequence: only the last tile can be clipped
     long long total_rows = 0;
@@ -699,14 +809,48 @@ int render_rows(rt_ctx* c, int y_start, int tile_rows, int stride_rows, int n_ti
         if (y0 >= H) break;
         total_rows += std::min<long long>(tile_rows, H - y0);
     }
-    const int rows_per_pass = (int)(c->ws.cap / W);
+    // Event timing and the counting instances book per launch into host-side sums and one device table:
+    // such calls run one at a time on the caller's stream.
+    const bool in_lanes = c->in_flight > 1 && !c->profile && !c->work_counters;
+    if (!in_lanes) {
+        int rc = ensure_workspace(c);
+        if (rc) return rc;
+        // (calls still in flight in lanes come first: pixels land in call order)
+        for (Lane* L : c->lanes)
+            if (L->pending) HIP_TRY(hipStreamWaitEvent(st, L->done, 0));
+        c->prev_done = nullptr;
+        const int rows_per_pass = (int)(c->ws.cap / W);
+        c->last_stream = st;
+        for (long long q0 = 0; q0 < total_rows; q0 += rows_per_pass) {
+            int nrows = (int)std::min<long long>(rows_per_pass, total_rows - q0);
+            PassDesc pd{y_start, tile_rows, stride_rows, (int)q0};
+            rc = run_pass(c, c->ws, pd, nrows, st);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    int rc = ensure_lanes(c);
+    if (rc) return rc;
+    Lane* L = c->lanes[c->seq % (unsigned long long)c->in_flight];
+    // behind what the caller's stream holds now (and, by stream order, behind the lane's previous call)
+    HIP_TRY(hipEventRecord(L->in, st));
+    HIP_TRY(hipStreamWaitEvent(L->main, L->in, 0));
+    const int rows_per_pass = (int)(L->ws.cap / W);
     c->last_stream = st;
-    for (long long q0 = 0; q0 < total_rows; q0 += rows_per_pass) {
+    c->cur = L;
+    for (long long q0 = 0; q0 < total_rows && rc == 0; q0 += rows_per_pass) {
         int nrows = (int)std::min<long long>(rows_per_pass, total_rows - q0);
         PassDesc pd{y_start, tile_rows, stride_rows, (int)q0};
-        rc = run_pass(c, c->ws, pd, nrows, st);
-        if (rc) return rc;
+        rc = run_pass(c, L->ws, pd, nrows, L->main);
     }
+    c->cur = nullptr;
+    // (also after a failed launch: what was enqueued still runs, and the next call's folds wait for it)
+    hipError_t e = hipEventRecord(L->done, L->main);
+    L->pending = true;
+    L->seq = c->seq++;
+    c->prev_done = L->done;
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("frames in flight: ") + hipGetErrorString(e));
     return 0;
 }
 
@@ -1592,6 +1736,9 @@ extern "C" {
 int rt_set_option(rt_ctx* c, int option, int64_t value) {
     if (!c) return fail(RT_ERR_ARG, "rt_set_option: null ctx");
     RT_GUARD_BEGIN
+    // (tables that an option rewrites must not be in use: calls in flight in lanes are waited for)
+    for (Lane* L : c->lanes)
+        if (L->pending) { HIP_TRY(hipSetDevice(c->device)); int rc = sync_all(c); if (rc) return rc; break; }
     switch (option) {
         case RT_OPT_EXACT_ONLY: c->force_exact = value ? 1 : 0; return 0;
         case RT_OPT_PROFILE: c->profile = value ? 1 : 0; return 0;
@@ -1613,6 +1760,15 @@ int rt_set_option(rt_ctx* c, int option, int64_t value) {
         case RT_OPT_OVERLAP: c->overlap = value ? 1 : 0; return 0;
         case RT_OPT_WORK_COUNTERS: c->work_counters = value ? 1 : 0; return 0;
         case RT_OPT_SCAN_COPIES: c->scan_copies = value ? 1 : 0; return 0;
+        case RT_OPT_FRAMES_IN_FLIGHT: {
+            if (value < 1 || value > 4) return fail(RT_ERR_ARG, "rt_set_option: 1 to 4 frames in flight");
+            HIP_TRY(hipSetDevice(c->device));
+            int rc = sync_all(c);
+            if (rc) return rc;
+            c->in_flight = (int)value;
+            if (c->in_flight == 1) drop_lanes(c);       // (their workspaces go back to the device)
+            return 0;
+        }
         case RT_OPT_BOUNDING_TESTS: c->pretest = value ? 1 : 0; c->pretest_any = value == 1 ? 1 : 0; return 0;
         case RT_OPT_USE_BVH:
             if (value) {
@@ -1641,6 +1797,18 @@ int rt_render_tiles(rt_ctx* c, int first_tile, int tile_rows, int tile_step, voi
     if (first_tile >= n_total) return 0;
     const int n_mine = (n_total - first_tile + tile_step - 1) / tile_step;
     return render_rows(c, first_tile * tile_rows, tile_rows, tile_step * tile_rows, n_mine, (hipStream_t)stream);
+}
+
+int rt_join(rt_ctx* c, void* stream, int keep_latest) {
+    if (!c) return fail(RT_ERR_ARG, "rt_join: null ctx");
+    if (keep_latest < 0) return fail(RT_ERR_ARG, "rt_join: keep_latest must not be negative");
+    RT_GUARD_BEGIN
+    HIP_TRY(hipSetDevice(c->device));
+    for (Lane* L : c->lanes)
+        if (L->pending && c->seq - L->seq > (unsigned long long)keep_latest)
+            HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, L->done, 0));
+    return 0;
+    RT_GUARD_END("rt_join")
 }
 
 int rt_render_tile_noalloc(rt_ctx* c, int y0, int rows, void* stream) {
@@ -1846,7 +2014,7 @@ int rt_download(rt_ctx* c, uint8_t* rgba, size_t bytes) {
     const size_t need = (size_t)c->hs.width * c->hs.height * 4;
     if (bytes < need) return fail(RT_ERR_RANGE, "rt_download: buffer too small");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->last_stream));
+    { int rc = sync_all(c); if (rc) return rc; }
     HIP_TRY(hipMemcpy(rgba, c->frame, need, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -1854,7 +2022,7 @@ int rt_download(rt_ctx* c, uint8_t* rgba, size_t bytes) {
 int rt_get_stats(rt_ctx* c, rt_stats* out) {
     if (!c || !out) return fail(RT_ERR_ARG, "rt_get_stats: null argument");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->last_stream));
+    { int rc = sync_all(c); if (rc) return rc; }
     drain_spans(c);
     DevCounters dc;
     HIP_TRY(hipMemcpy(&dc, c->counters.p, sizeof dc, hipMemcpyDeviceToHost));
@@ -1868,6 +2036,13 @@ int rt_get_stats(rt_ctx* c, rt_stats* out) {
         HIP_TRY(hipMemcpy(tally.data(), c->bvh_tally.p, tally.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         for (size_t b = 0; b < tally.size(); b += 4) {
             out->bvh_node_tests += tally[b]; out->bvh_leaf_tests += tally[b + 1]; out->exact_tests += tally[b + 2];
+        }
+        for (Lane* L : c->lanes) {
+            if (!L->bvh_tally.p) continue;
+            HIP_TRY(hipMemcpy(tally.data(), L->bvh_tally.p, tally.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            for (size_t b = 0; b < tally.size(); b += 4) {
+                out->bvh_node_tests += tally[b]; out->bvh_leaf_tests += tally[b + 1]; out->exact_tests += tally[b + 2];
+            }
         }
     }
     out->in_plane_origin_hits = dc.in_plane_origin_hits; out->flagged_rays = dc.flagged_rays;
@@ -1888,12 +2063,14 @@ int rt_get_stats(rt_ctx* c, rt_stats* out) {
 int rt_reset_stats(rt_ctx* c) {
     if (!c) return fail(RT_ERR_ARG, "rt_reset_stats: null ctx");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->last_stream));
+    { int rc = sync_all(c); if (rc) return rc; }
     drain_spans(c);
     for (int k = 0; k <= RT_WORK_KINDS; k++) { c->ms[k] = 0; c->launches[k] = 0; }
     HIP_TRY(hipMemset(c->counters.p, 0, sizeof(DevCounters)));
     HIP_TRY(hipMemset(c->work.p, 0, RT_WORK_KINDS * RT_WORK_FIELDS * sizeof(unsigned long long)));
     if (c->bvh_tally.p) HIP_TRY(hipMemset(c->bvh_tally.p, 0, 2 * (size_t)c->aux_grid * 4 * sizeof(unsigned long long)));
+    for (Lane* L : c->lanes)
+        if (L->bvh_tally.p) HIP_TRY(hipMemset(L->bvh_tally.p, 0, 2 * (size_t)c->aux_grid * 4 * sizeof(unsigned long long)));
     return 0;
 }
 
@@ -1916,6 +2093,7 @@ void rt_free(rt_ctx* c) {
     c->obj_normals.release(); c->materials.release(); c->lights.release(); c->own_frame.release();
     c->counters.release(); c->work.release();
     c->ws_block.release();
+    drop_lanes(c);
     for (auto e : c->ev_hit) (void)hipEventDestroy(e);
     for (auto e : c->ev_phong) (void)hipEventDestroy(e);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);

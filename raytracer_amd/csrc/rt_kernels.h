@@ -2243,10 +2243,11 @@ __global__ void k_count(const DevScene* __restrict__ sc, const uint32_t* __restr
     unsigned long long prims = (unsigned long long)sc->n_prims_nominal;
     unsigned long long rays = 0, hits = 0;
     for (int k = 0; k < levels; k++) { rays += counts[k]; hits += counts[k + 1]; }
-    c->rays_primary += counts[0];
-    c->rays_reflect += rays - counts[0];
-    c->rays_shadow += hits * (unsigned long long)sc->n_lights;
-    c->hits += hits;
-    c->closest_tests += rays * prims;
-    c->anyhit_tests += hits * (unsigned long long)sc->n_lights * prims;
+    // (atomic: passes of several render calls in flight end side by side)
+    atomicAdd(&c->rays_primary, (unsigned long long)counts[0]);
+    atomicAdd(&c->rays_reflect, rays - counts[0]);
+    atomicAdd(&c->rays_shadow, hits * (unsigned long long)sc->n_lights);
+    atomicAdd(&c->hits, hits);
+    atomicAdd(&c->closest_tests, rays * prims);
+    atomicAdd(&c->anyhit_tests, hits * (unsigned long long)sc->n_lights * prims);
 }

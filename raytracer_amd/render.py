@@ -52,6 +52,11 @@ class Renderer:
         _check(self._lib, self._lib.rt_render_tiles(self._ctx, int(first_tile), int(tile_rows), int(tile_step),
                                                     C.c_void_p(stream or 0)), "rt_render_tiles")
 
+    def join(self, stream=None, keep_latest=0):
+        """RT_OPT_FRAMES_IN_FLIGHT > 1: `stream` waits (on the device) for all render calls issued so far but the
+        `keep_latest` most recent ones."""
+        _check(self._lib, self._lib.rt_join(self._ctx, C.c_void_p(stream or 0), int(keep_latest)), "rt_join")
+
     def render_frame(self, stream=None):
         self.render_tile(0, self.height, stream)
 

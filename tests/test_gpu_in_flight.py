@@ -1,0 +1,178 @@
+"""Several render calls in flight (RT_OPT_FRAMES_IN_FLIGHT, rt_join).
+
+A call in flight runs on streams and in a workspace of its own; nothing about the pixels may
+change: the frames must be byte-identical to those of one call at a time, the counters must add
+up, pixels written by several calls must land in call order, and rt_join must make the
+caller's stream see exactly the calls it names.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from raytracer_amd import Scene, abi
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COUNTS = ("rays_primary", "rays_reflect", "rays_shadow", "hits", "closest_tests", "anyhit_tests")
+
+
+def one_at_a_time(sc, bvh=0):
+    from raytracer_amd.render import Renderer
+    r = Renderer(sc)
+    if bvh:
+        r.set_option(abi.RT_OPT_USE_BVH, bvh)
+    r.render_frame()
+    img, st = r.download(), r.stats()
+    r.close()
+    return img, st
+
+
+@pytest.mark.parametrize("name,w,h,depth,bvh", [
+    ("teapot.scene", 640, 360, 5, 0), ("teapot.scene", 640, 360, 5, 1), ("mixed_xf.scene", 320, 240, 6, 0),
+    ("inputs/input-06", 200, 200, 6, 0), ("campanile_teddy.scene", 256, 144, 3, 1),
+])
+@pytest.mark.parametrize("in_flight", [2, 3, 4])
+def test_frames_in_flight_give_the_same_frame(name, w, h, depth, bvh, in_flight):
+    from raytracer_amd.render import Renderer
+    sc = Scene.load(os.path.join(ROOT, "scenes", name), w, h, depth)
+    want, st1 = one_at_a_time(sc, bvh)
+    r = Renderer(sc)
+    if bvh:
+        r.set_option(abi.RT_OPT_USE_BVH, bvh)
+    r.set_option(abi.RT_OPT_FRAMES_IN_FLIGHT, in_flight)
+    n = 7
+    for _ in range(n):
+        r.render_frame()
+    got, st = r.download(), r.stats()
+    assert np.array_equal(got, want), int((got != want).any(axis=-1).sum())
+    for k in COUNTS:
+        assert st[k] == n * st1[k], k
+    if not bvh:
+        assert st["in_plane_origin_hits"] == n * st1["in_plane_origin_hits"]
+    else:
+        assert st["bvh_node_tests"] == n * st1["bvh_node_tests"] and st["bvh_leaf_tests"] == n * st1["bvh_leaf_tests"]
+    # back to one call at a time on the same context: the same frame again
+    r.set_option(abi.RT_OPT_FRAMES_IN_FLIGHT, 1)
+    r.render_frame()
+    assert np.array_equal(r.download(), want)
+    r.close()
+
+
+class Hip:
+    """The few HIP runtime calls the hand-over test needs, from the runtime the library itself is linked against
+    (no torch here: its own copy of the runtime must not be initialised after this one in the same process)."""
+
+    def __init__(self):
+        self.lib = C.CDLL("/opt/rocm/lib/libamdhip64.so")
+        self.lib.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.lib.hipFree.argtypes = [C.c_void_p]
+        self.lib.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+        self.lib.hipStreamDestroy.argtypes = [C.c_void_p]
+        self.lib.hipStreamSynchronize.argtypes = [C.c_void_p]
+        self.lib.hipMemsetAsync.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+        self.lib.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+
+    def ok(self, rc):
+        assert rc == 0, f"HIP error {rc}"
+
+    def malloc(self, n):
+        p = C.c_void_p()
+        self.ok(self.lib.hipMalloc(C.byref(p), n))
+        return p.value
+
+    def stream(self):
+        s = C.c_void_p()
+        self.ok(self.lib.hipStreamCreate(C.byref(s)))
+        return s.value
+
+
+def test_a_frame_buffer_per_call_and_join():
+    """Three frame buffers, three calls in flight, each handed on (copied on the caller's stream) while the next
+    ones are traced: rt_join(stream, keep_latest) must order the copy behind the call that wrote the buffer, and a
+    call must come behind what the caller's stream held when it was issued (here: a fill of its buffer)."""
+    from raytracer_amd.render import Renderer
+    hip = Hip()
+    sc = Scene.load(os.path.join(ROOT, "scenes", "teapot.scene"), 960, 540, 5)
+    want, _ = one_at_a_time(sc)
+    nbytes = want.nbytes
+    r = Renderer(sc)
+    k, calls = 3, 8
+    r.set_option(abi.RT_OPT_FRAMES_IN_FLIGHT, k)
+    frames = [hip.malloc(nbytes) for _ in range(k)]
+    handed_on = [hip.malloc(nbytes) for _ in range(calls)]
+    stream = hip.stream()
+    lib = r._lib
+    pending, out = [], 0
+    for i in range(calls):
+        f = frames[i % k]
+        hip.ok(hip.lib.hipMemsetAsync(f, 7, nbytes, stream))
+        assert lib.rt_bind_frame(r._ctx, C.c_void_p(f), nbytes) == 0
+        r.render_frame(stream)
+        pending.append(f)
+        if len(pending) == k:
+            r.join(stream, keep_latest=k - 1)
+            hip.ok(hip.lib.hipMemcpyAsync(handed_on[out], pending.pop(0), nbytes, 3, stream))      # device to device
+            out += 1
+    r.join(stream, 0)
+    for f in pending:
+        hip.ok(hip.lib.hipMemcpyAsync(handed_on[out], f, nbytes, 3, stream))
+        out += 1
+    hip.ok(hip.lib.hipStreamSynchronize(stream))
+    assert out == calls
+    got = np.empty_like(want)
+    for i in range(calls):
+        hip.ok(hip.lib.hipMemcpyAsync(got.ctypes.data_as(C.c_void_p), handed_on[i], nbytes, 2, stream))   # device to host
+        hip.ok(hip.lib.hipStreamSynchronize(stream))
+        assert np.array_equal(got, want), i
+    assert lib.rt_bind_frame(r._ctx, None, 0) == 0
+    r.close()
+    for p in frames + handed_on:
+        hip.ok(hip.lib.hipFree(p))
+    hip.ok(hip.lib.hipStreamDestroy(stream))
+
+
+def test_calls_on_different_rows_land_in_call_order():
+    """Tiles of one frame as separate calls in flight, then the whole frame once more with another depth bound to
+    the same buffer: the last call's pixels must be the ones that stay."""
+    from raytracer_amd.render import Renderer
+    sc = Scene.load(os.path.join(ROOT, "scenes", "teapot.scene"), 480, 272, 5)
+    want, _ = one_at_a_time(sc)
+    r = Renderer(sc)
+    r.set_option(abi.RT_OPT_FRAMES_IN_FLIGHT, 3)
+    for rank in range(5):
+        r.render_tiles(rank, 16, 5)
+    assert np.array_equal(r.download(), want)
+    # the same rows again and again: every call clears and rewrites them, the frame stays the frame
+    for _ in range(4):
+        r.render_tile(100, 60)
+    assert np.array_equal(r.download(), want)
+    # event timing runs one call at a time; calls in flight before it must come first
+    r.render_frame()
+    r.set_option(abi.RT_OPT_PROFILE, 1)
+    r.render_frame()
+    r.set_option(abi.RT_OPT_PROFILE, 0)
+    r.render_frame()
+    assert np.array_equal(r.download(), want)
+    with pytest.raises(Exception):
+        r.set_option(abi.RT_OPT_FRAMES_IN_FLIGHT, 5)
+    r.close()
+
+
+def test_small_passes_in_flight():
+    """Calls that need several passes each (a small RT_OPT_PASS_PIXELS) keep their passes in their own lane."""
+    from raytracer_amd.render import Renderer
+    sc = Scene.load(os.path.join(ROOT, "scenes", "mixed_xf.scene"), 320, 240, 6)
+    want, st1 = one_at_a_time(sc)
+    r = Renderer(sc)
+    r.set_option(abi.RT_OPT_PASS_PIXELS, 320 * 50)
+    r.set_option(abi.RT_OPT_FRAMES_IN_FLIGHT, 2)
+    for _ in range(5):
+        r.render_frame()
+    got, st = r.download(), r.stats()
+    assert np.array_equal(got, want)
+    for k in COUNTS:
+        assert st[k] == 5 * st1[k], k
+    r.close()
