@@ -72,6 +72,11 @@ def parse():
                          "rehearse the N-rank flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-config5", action="store_true",
                     help="skip the roofline-stress leg (1,000,000 triangles + 64 spheres, 16 lights, depth 8)")
+    ap.add_argument("--frames-in-flight", type=int, default=3,
+                    help="render calls in flight in the timed region (RT_OPT_FRAMES_IN_FLIGHT, 1..4): frame i+1 is traced "
+                         "beside the deep levels of frame i, each in a frame buffer of its own; 1 = one frame at a time")
+    ap.add_argument("--dump-frame", default=None,
+                    help="rank 0 writes the last frame of the timed region (after its exchange) to this .npy file")
     ap.add_argument("--no-overlap", action="store_true",
                     help="one stream: no overlap of a level's shadow launches with the next level's nearest-hit launches")
     return ap.parse_args()
@@ -235,18 +240,51 @@ def main():
     r = Renderer(scene)
     if args.exact_only:
         r.set_option(abi.RT_OPT_EXACT_ONLY, 1)
-    frame = torch.zeros((args.height, args.width, 4), dtype=torch.uint8, device=dev)
+    in_flight = max(1, min(4, args.frames_in_flight))
+    # one frame buffer per render call in flight: frame i is exchanged while frame i+1 is traced
+    frames = [torch.zeros((args.height, args.width, 4), dtype=torch.uint8, device=dev) for _ in range(in_flight)]
+    frame = frames[0]
     r.bind_frame(frame)
     stream = torch.cuda.current_stream().cuda_stream
     exchange = TileGather(args.height, args.width, args.tile_rows, rank, world, dev, dist=dist, torch=torch,
                           host_staging=args.backend != "nccl")
     coll_dev = dev if args.backend == "nccl" else torch.device("cpu")      # where the small reductions live
+    state = {"calls": 0, "lanes": 1, "waiting": []}       # frames traced (or being traced) and not yet exchanged
+
+    def set_in_flight(k):
+        drain()
+        r.set_option(abi.RT_OPT_FRAMES_IN_FLIGHT, k)
+        state["lanes"] = k
+        if k == 1:
+            r.bind_frame(frame)
 
     def step():
+        """One frame: this rank's tiles traced, the frame exchanged.  With k frames in flight the exchange of a
+        frame is issued k - 1 steps after its render call (behind rt_join on this stream), beside the tracing of
+        the frames after it; drain() issues what is left.  K steps + drain() = K frames traced and exchanged."""
+        k = state["lanes"]
+        if k == 1:
+            r.render_tiles(rank, args.tile_rows, world, stream)
+            exchange(frame)
+            return
+        f = frames[state["calls"] % k]
+        state["calls"] += 1
+        r.bind_frame(f)
         r.render_tiles(rank, args.tile_rows, world, stream)
-        exchange(frame)
+        state["waiting"].append(f)
+        if len(state["waiting"]) == k:
+            r.join(stream, k - 1)
+            exchange(state["waiting"].pop(0))
+
+    def drain():
+        if state["waiting"]:
+            r.join(stream, 0)
+            for f in state["waiting"]:
+                exchange(f)
+            state["waiting"].clear()
 
     def fence():
+        drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -254,7 +292,16 @@ def main():
 
     if args.no_overlap:
         r.set_option(abi.RT_OPT_OVERLAP, 0)
-    for _ in range(args.warmup):
+    # One frame at a time first (its time is the latency of a frame), then the timed region with frames in flight.
+    step()
+    fence()
+    tl = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    one_at_a_time_ms = (time.perf_counter() - tl) / args.steps * 1e3
+    set_in_flight(in_flight)
+    for _ in range(max(args.warmup, in_flight if in_flight > 1 else 0)):      # (every lane's workspace is in place)
         step()
     fence()
     r.reset_stats()
@@ -265,6 +312,11 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     st_timed = r.stats()
+    if args.dump_frame and rank == 0:
+        import numpy as np
+        last = frames[(state["calls"] - 1) % in_flight] if in_flight > 1 else frame
+        np.save(args.dump_frame, last.cpu().numpy())
+    set_in_flight(1)
 
     # Kernel durations for the roofline: the same K frames once more with HIP events around every
     # trace-kernel launch (recorded by the library on the launch stream).  Event timing serialises
@@ -314,6 +366,15 @@ def main():
         r.set_option(abi.RT_OPT_USE_BVH, 1)
         step()
         fence()
+        tb = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        lb_one_ms = (time.perf_counter() - tb) / args.steps * 1e3
+        set_in_flight(in_flight)
+        for _ in range(max(1, in_flight if in_flight > 1 else 0)):
+            step()
+        fence()
         r.reset_stats()
         fence()
         tb = time.perf_counter()
@@ -322,16 +383,18 @@ def main():
         fence()
         lb_elapsed = time.perf_counter() - tb
         sb = r.stats()
+        set_in_flight(1)
         r.set_option(abi.RT_OPT_USE_BVH, 0)
         lb_rays = sb["rays_primary"] + sb["rays_reflect"] + sb["rays_shadow"]
         if world > 1:
-            tt = torch.tensor([lb_elapsed, float(lb_rays)], dtype=torch.float64, device=coll_dev)
+            tt = torch.tensor([lb_elapsed, float(lb_rays), lb_one_ms], dtype=torch.float64, device=coll_dev)
             mx = tt.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
             sm = tt.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-            lb_elapsed, lb_rays_total = float(mx[0].item()), float(sm[1].item())
+            lb_elapsed, lb_rays_total, lb_one_ms = float(mx[0].item()), float(sm[1].item()), float(mx[2].item())
         else:
             lb_rays_total = float(lb_rays)
         lbvh = {"value": lb_rays_total / lb_elapsed / 1e6, "unit": "Mrays/s", "ms_per_step": lb_elapsed / args.steps * 1e3,
+                "frames_in_flight": in_flight, "one_frame_at_a_time_ms": lb_one_ms,
                 "box_tests_per_ray": sb["bvh_node_tests"] / max(1, lb_rays),
                 "leaf_tests_per_ray": sb["bvh_leaf_tests"] / max(1, lb_rays),
                 "exact_retests_per_ray": sb["exact_tests"] / max(1, lb_rays),
@@ -339,9 +402,9 @@ def main():
 
     rays_local = st_timed["rays_primary"] + st_timed["rays_reflect"] + st_timed["rays_shadow"]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+        t = torch.tensor([elapsed, one_at_a_time_ms], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, one_at_a_time_ms = float(t[0].item()), float(t[1].item())
         cnt = torch.tensor([rays_local, st_timed["rays_primary"], st_timed["rays_reflect"], st_timed["rays_shadow"]],
                            dtype=torch.int64, device=coll_dev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
@@ -427,6 +490,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "one_frame_at_a_time_ms": one_at_a_time_ms,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -434,6 +498,12 @@ def main():
             "data": "synthetic (teapot.obj mesh + 2 floor triangles, authored scene file)",
             "config": {"workload": f"{os.path.basename(args.scene)} {args.width}x{args.height} depth {args.depth}",
                        "streams": "one" if args.no_overlap else "two (shadow launches beside the next level's nearest-hit launches)",
+                       "frames_in_flight": in_flight,
+                       "frames_in_flight_note": "render call i+1 is enqueued while call i runs (RT_OPT_FRAMES_IN_FLIGHT): the short "
+                                                "launches of a frame's deep levels share the chip with the next frame's large ones; "
+                                                "every frame is traced in full into a buffer of its own and exchanged, none is skipped "
+                                                "or reused; ms_per_step is time per frame at that throughput, one_frame_at_a_time_ms the "
+                                                "same K frames with one call in flight",
                        "triangles": n_tri, "spheres": n_sph, "lights": scene.desc.n_lights,
                        "tile_rows": args.tile_rows, "parallelism": f"interleaved scanline tiles x{world}",
                        "rays_per_frame": {"primary": n_primary // args.steps, "reflect": n_reflect // args.steps,

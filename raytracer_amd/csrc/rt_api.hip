@@ -219,8 +219,15 @@ struct rt_ctx {
     // RT_OPT_FRAMES_IN_FLIGHT: render call i runs in lanes[i % in_flight] (none of this is used at 1)
     int in_flight = 1;
     std::vector<Lane*> lanes;
+    // The lanes' streams, created once and kept until rt_free: which hardware queue a stream lands on is decided
+    // when it is first used, and streams that share a queue do not overlap -- an arrangement that overlaps is kept.
+    std::vector<hipStream_t> lane_streams;
     Lane* cur = nullptr;                  // the lane of the call being enqueued (null: the context's own resources)
-    hipEvent_t prev_done = nullptr;       // `done` of the previous call in flight: the folds keep call order
+    // `done` of the previous call in flight and the frame it wrote: a call that writes the same buffer runs its
+    // folds behind it, so that pixels land in call order.  (Calls that write different buffers are not tied to each
+    // other; measured, tying them costs nothing either.)
+    hipEvent_t prev_done = nullptr;
+    uint32_t* prev_frame = nullptr;
     unsigned long long seq = 0;           // render calls issued in lanes so far
 
     // host copies kept so that the filter form can be switched after the upload
@@ -443,9 +450,7 @@ void release_lane(Lane* L) {
     for (auto e : L->ev_phong) (void)hipEventDestroy(e);
     if (L->in) (void)hipEventDestroy(L->in);
     if (L->done) (void)hipEventDestroy(L->done);
-    if (L->main) (void)hipStreamDestroy(L->main);
-    if (L->side) (void)hipStreamDestroy(L->side);
-    delete L;             // (the buffers release themselves)
+    delete L;             // (the buffers release themselves; the streams belong to the context)
 }
 
 // Host-side wait for everything the context has enqueued: the last caller's stream and every lane.
@@ -483,8 +488,14 @@ int ensure_lanes(rt_ctx* c) {
     while ((int)c->lanes.size() < c->in_flight) {
         Lane* L = new Lane;
         auto give_up = [&](int code, const std::string& msg) { release_lane(L); return fail(code, msg); };
-        hipError_t e = hipStreamCreateWithFlags(&L->main, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&L->side, hipStreamNonBlocking);
+        hipError_t e = hipSuccess;
+        const size_t at = 2 * c->lanes.size();
+        while (c->lane_streams.size() < at + 2 && e == hipSuccess) {
+            hipStream_t s = nullptr;
+            e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+            if (e == hipSuccess) c->lane_streams.push_back(s);
+        }
+        if (e == hipSuccess) { L->main = c->lane_streams[at]; L->side = c->lane_streams[at + 1]; }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&L->in, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&L->done, hipEventDisableTiming);
         for (int k = 0; k < 2 * levels && e == hipSuccess; k++) {
@@ -784,7 +795,7 @@ int run_pass(rt_ctx* c, const Workspace& ws, PassDesc pd, int nrows, hipStream_t
     // the fold (and whatever the caller enqueues next) comes after everything on the side stream
     if (overlap) HIP_TRY(hipStreamWaitEvent(st, ev_phong[levels - 1], 0));
     // ... and, with several calls in flight, after the folds of the call before this one: pixels land in call order
-    if (c->cur && c->prev_done) HIP_TRY(hipStreamWaitEvent(st, c->prev_done, 0));
+    if (c->cur && c->prev_done && c->prev_frame == c->frame) HIP_TRY(hipStreamWaitEvent(st, c->prev_done, 0));
     for (int k = levels - 1; k >= 0; k--) {
         FoldArgs fa{};
         fa.sc = dsc; fa.lvl = level_of(ws, k); fa.parent_lvl = level_of(ws, k > 0 ? k - 1 : 0);
@@ -849,6 +860,7 @@ int render_rows(rt_ctx* c, int y_start, int tile_rows, int stride_rows, int n_ti
     L->pending = true;
     L->seq = c->seq++;
     c->prev_done = L->done;
+    c->prev_frame = c->frame;
     if (rc) return rc;
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("frames in flight: ") + hipGetErrorString(e));
     return 0;
@@ -2094,6 +2106,7 @@ void rt_free(rt_ctx* c) {
     c->counters.release(); c->work.release();
     c->ws_block.release();
     drop_lanes(c);
+    for (auto st : c->lane_streams) (void)hipStreamDestroy(st);
     for (auto e : c->ev_hit) (void)hipEventDestroy(e);
     for (auto e : c->ev_phong) (void)hipEventDestroy(e);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);

@@ -135,14 +135,27 @@ def test_two_rank_benchmark_flow_on_one_gpu():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    common = ["--steps", "1", "--warmup", "0", "--width", "640", "--height", "360", "--no-cpu-baseline", "--no-lbvh", "--no-config5"]
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common,
-                         check=True, capture_output=True, text=True, timeout=300).stdout
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-                          "--gpus", "2", "--backend", "gloo"] + common,
-                         check=True, capture_output=True, text=True, timeout=300).stdout
-    a = json.loads(one.strip().splitlines()[-1])
-    b = json.loads([ln for ln in two.strip().splitlines() if ln.startswith("{")][-1])
-    assert a["n_gpus"] == 1 and b["n_gpus"] == 2 and b["value"] > 0
-    assert a["config"]["rays_per_frame"] == b["config"]["rays_per_frame"]
+    import tempfile
+    common = ["--steps", "4", "--warmup", "0", "--width", "640", "--height", "360", "--no-cpu-baseline", "--no-lbvh", "--no-config5"]
+    with tempfile.TemporaryDirectory() as tmp:
+        f1, f2, f3 = (os.path.join(tmp, n) for n in ("one.npy", "two.npy", "two_serial.npy"))
+        one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dump-frame", f1] + common,
+                             check=True, capture_output=True, text=True, timeout=300).stdout
+        launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                  "--gpus", "2", "--backend", "gloo"]
+        # three frames in flight per rank (the default): a frame is exchanged two steps after its render call
+        two = subprocess.run(launch + ["--dump-frame", f2] + common, check=True, capture_output=True, text=True, timeout=300).stdout
+        # ... and one frame at a time
+        subprocess.run(launch + ["--dump-frame", f3, "--frames-in-flight", "1"] + common, check=True, capture_output=True,
+                       text=True, timeout=300)
+        a = json.loads(one.strip().splitlines()[-1])
+        b = json.loads([ln for ln in two.strip().splitlines() if ln.startswith("{")][-1])
+        assert a["n_gpus"] == 1 and b["n_gpus"] == 2 and b["value"] > 0
+        assert a["config"]["rays_per_frame"] == b["config"]["rays_per_frame"]
+        assert a["config"]["frames_in_flight"] == 3 and b["config"]["frames_in_flight"] == 3
+        # rank 0's frame after the exchange is the single-process frame, byte for byte
+        want = np.load(f1)
+        assert want.any()
+        assert np.array_equal(np.load(f2), want)
+        assert np.array_equal(np.load(f3), want)
