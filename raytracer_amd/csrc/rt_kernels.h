@@ -1200,15 +1200,23 @@ __device__ __forceinline__ float uniform_f(float x) {      // a value every lane
 }
 
 template <int MODE, int RPL, bool ROBUST, int CONE, bool WORK = false>
-// (Four waves per SIMD for the camera and shadow instances -- 128 registers, 3 and 10 of them spilled to scratch --
-// made the shadow scan 3.5 % faster on its own and the frame no faster: the two streams already fill the idle slots.)
+// The bounded instances are compiled for four waves per SIMD (128 registers; a few values spill to scratch).  Timed
+// alone a scan gains 3-6 % from the fourth wave and the frame nothing while one frame is in flight (the second
+// stream already fills the idle slots); with three frames in flight, where the sum of the work counts, the frame
+// gains 2 % (5.58 -> 5.45 ms).  Five and six waves (with fewer rays per lane to make room) measured slower.
+#ifndef RT_MIN_WAVES_BOUNDED
+#define RT_MIN_WAVES_BOUNDED 4
+#endif
 #ifndef RT_MIN_WAVES_CAMERA
-#define RT_MIN_WAVES_CAMERA RT_FILTER_MIN_WAVES
+#define RT_MIN_WAVES_CAMERA RT_MIN_WAVES_BOUNDED
 #endif
 #ifndef RT_MIN_WAVES_SHADOW
-#define RT_MIN_WAVES_SHADOW RT_FILTER_MIN_WAVES
+#define RT_MIN_WAVES_SHADOW RT_MIN_WAVES_BOUNDED
 #endif
-__global__ void __launch_bounds__(RT_BLOCK, (CONE == 1 ? RT_MIN_WAVES_CAMERA : CONE == 2 ? RT_MIN_WAVES_SHADOW : RT_FILTER_MIN_WAVES))
+#ifndef RT_MIN_WAVES_ANY
+#define RT_MIN_WAVES_ANY RT_MIN_WAVES_BOUNDED
+#endif
+__global__ void __launch_bounds__(RT_BLOCK, (CONE == 1 ? RT_MIN_WAVES_CAMERA : CONE == 2 ? RT_MIN_WAVES_SHADOW : CONE == 4 ? RT_MIN_WAVES_ANY : RT_FILTER_MIN_WAVES))
 k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, TraceArgs A) {
     // The filter records are never written while a kernel runs: reading them through the
     // constant address space lets the compiler use scalar loads (s_load_dwordx16).
