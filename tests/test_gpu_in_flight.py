@@ -62,11 +62,15 @@ def test_frames_in_flight_give_the_same_frame(name, w, h, depth, bvh, in_flight)
 
 
 class Hip:
-    """The few HIP runtime calls the hand-over test needs, from the runtime the library itself is linked against
-    (no torch here: its own copy of the runtime must not be initialised after this one in the same process)."""
+    """The few HIP runtime calls the hand-over test needs, from the copy of the runtime that the library itself
+    uses in this process (whichever libamdhip64 was mapped first: a second copy must not be loaded beside it)."""
 
     def __init__(self):
-        self.lib = C.CDLL("/opt/rocm/lib/libamdhip64.so")
+        from raytracer_amd import abi as _abi
+        _abi.device_lib()
+        mapped = [ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64.so" in ln]
+        assert mapped, "the device library is loaded, so a HIP runtime must be mapped"
+        self.lib = C.CDLL(mapped[0])
         self.lib.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
         self.lib.hipFree.argtypes = [C.c_void_p]
         self.lib.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
