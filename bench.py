@@ -220,7 +220,7 @@ def main():
     import torch
     import torch.distributed as dist
     from raytracer_amd import Scene, abi
-    from raytracer_amd.render import Renderer, TileGather
+    from raytracer_amd.render import FramePipeline, Renderer, TileGather
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -243,45 +243,12 @@ def main():
     in_flight = max(1, min(4, args.frames_in_flight))
     # one frame buffer per render call in flight: frame i is exchanged while frame i+1 is traced
     frames = [torch.zeros((args.height, args.width, 4), dtype=torch.uint8, device=dev) for _ in range(in_flight)]
-    frame = frames[0]
-    r.bind_frame(frame)
     stream = torch.cuda.current_stream().cuda_stream
     exchange = TileGather(args.height, args.width, args.tile_rows, rank, world, dev, dist=dist, torch=torch,
                           host_staging=args.backend != "nccl")
     coll_dev = dev if args.backend == "nccl" else torch.device("cpu")      # where the small reductions live
-    state = {"calls": 0, "lanes": 1, "waiting": []}       # frames traced (or being traced) and not yet exchanged
-
-    def set_in_flight(k):
-        drain()
-        r.set_option(abi.RT_OPT_FRAMES_IN_FLIGHT, k)
-        state["lanes"] = k
-        if k == 1:
-            r.bind_frame(frame)
-
-    def step():
-        """One frame: this rank's tiles traced, the frame exchanged.  With k frames in flight the exchange of a
-        frame is issued k - 1 steps after its render call (behind rt_join on this stream), beside the tracing of
-        the frames after it; drain() issues what is left.  K steps + drain() = K frames traced and exchanged."""
-        k = state["lanes"]
-        if k == 1:
-            r.render_tiles(rank, args.tile_rows, world, stream)
-            exchange(frame)
-            return
-        f = frames[state["calls"] % k]
-        state["calls"] += 1
-        r.bind_frame(f)
-        r.render_tiles(rank, args.tile_rows, world, stream)
-        state["waiting"].append(f)
-        if len(state["waiting"]) == k:
-            r.join(stream, k - 1)
-            exchange(state["waiting"].pop(0))
-
-    def drain():
-        if state["waiting"]:
-            r.join(stream, 0)
-            for f in state["waiting"]:
-                exchange(f)
-            state["waiting"].clear()
+    pipe = FramePipeline(r, frames, exchange, rank, world, args.tile_rows, stream)
+    step, drain, set_in_flight = pipe.step, pipe.drain, pipe.set_in_flight
 
     def fence():
         drain()
@@ -314,8 +281,7 @@ def main():
     st_timed = r.stats()
     if args.dump_frame and rank == 0:
         import numpy as np
-        last = frames[(state["calls"] - 1) % in_flight] if in_flight > 1 else frame
-        np.save(args.dump_frame, last.cpu().numpy())
+        np.save(args.dump_frame, pipe.last_frame().cpu().numpy())
     set_in_flight(1)
 
     # Kernel durations for the roofline: the same K frames once more with HIP events around every

@@ -192,6 +192,70 @@ class TileGather:
         return frame
 
 
+class FramePipeline:
+    """A sequence of frames on one rank of N with up to `in_flight` render calls in flight
+    (RT_OPT_FRAMES_IN_FLIGHT): frame i is traced into buffer i mod in_flight, and its exchange is issued
+    in_flight - 1 steps later -- behind rt_join(stream, in_flight - 1) on the caller's stream, beside the
+    tracing of the frames after it.  drain() issues what is left; step() K times + drain() = K frames
+    traced and exchanged, each exactly once and in order.  With in_flight = 1 every step traces and
+    exchanges its frame at once, into frames[0].
+
+    `renderer` needs set_option, bind_frame, render_tiles and join (Renderer has them); `exchange(frame)`
+    is a TileGather; `on_frame(index, frame)`, if given, is called right behind the exchange of each frame
+    (work it enqueues on the caller's stream sees the exchanged frame)."""
+
+    def __init__(self, renderer, frames, exchange, rank, world, tile_rows, stream=None, on_frame=None):
+        self.r, self.frames, self.exchange = renderer, list(frames), exchange
+        self.rank, self.world, self.tile_rows, self.stream = rank, world, tile_rows, stream
+        self.on_frame = on_frame
+        self.lanes = 1
+        self.calls = 0            # render calls issued
+        self.done = 0             # frames exchanged
+        self.waiting = []         # frames traced (or being traced) and not yet exchanged, oldest first
+        self.r.bind_frame(self.frames[0])
+
+    def set_in_flight(self, k):
+        """Exchanges what is waiting, then switches to k calls in flight (1 <= k <= len(frames))."""
+        if not 1 <= k <= len(self.frames):
+            raise ValueError(f"{k} calls in flight need {k} frame buffers, {len(self.frames)} given")
+        self.drain()
+        self.r.set_option(abi.RT_OPT_FRAMES_IN_FLIGHT, k)
+        self.lanes = k
+        self.r.bind_frame(self.frames[0])
+
+    def _hand_on(self, frame):
+        self.exchange(frame)
+        if self.on_frame is not None:
+            self.on_frame(self.done, frame)
+        self.done += 1
+
+    def step(self):
+        k = self.lanes
+        frame = self.frames[self.calls % k]
+        if k > 1:
+            self.r.bind_frame(frame)
+        self.calls += 1
+        self.r.render_tiles(self.rank, self.tile_rows, self.world, self.stream)
+        if k == 1:
+            self._hand_on(frame)
+            return
+        self.waiting.append(frame)
+        if len(self.waiting) == k:
+            self.r.join(self.stream, k - 1)
+            self._hand_on(self.waiting.pop(0))
+
+    def drain(self):
+        if self.waiting:
+            self.r.join(self.stream, 0)
+            for frame in self.waiting:
+                self._hand_on(frame)
+            self.waiting = []
+
+    def last_frame(self):
+        """The buffer of the most recent render call."""
+        return self.frames[(self.calls - 1) % self.lanes] if self.calls else self.frames[0]
+
+
 def gather_frame(renderer, frame, tile_rows, rank, world, dist=None, torch=None):
     """One-shot form of TileGather."""
     g = TileGather(frame.shape[0], frame.shape[1], tile_rows, rank, world, frame.device, dist=dist, torch=torch)

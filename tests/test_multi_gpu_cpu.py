@@ -92,3 +92,82 @@ def test_tile_spans_map_tiles_to_frame_rows(world, H, W, T):
     from raytracer_amd import abi
     off, nb = C.c_size_t(), C.c_size_t()
     assert abi.host_lib().rth_tile_span(W, H, T, world, len(spans), C.byref(off), C.byref(nb)) < 0
+
+
+class _StandInRenderer:
+    """What FramePipeline needs of a Renderer, on CPU tensors: render call c writes the rows this rank owns with
+    a pattern that encodes c, into the buffer bound at the time of the call; rt_join is recorded."""
+
+    def __init__(self, H, W, tile_rows):
+        self.H, self.W, self.tile_rows = H, W, tile_rows
+        self.bound, self.calls, self.in_flight, self.joined_up_to, self.log = None, 0, 1, 0, []
+
+    def set_option(self, option, value):
+        from raytracer_amd import abi
+        assert option == abi.RT_OPT_FRAMES_IN_FLIGHT
+        self.in_flight = value
+        self.joined_up_to = self.calls          # (the library waits for queued work when the option changes)
+
+    def bind_frame(self, frame):
+        self.bound = frame
+
+    def render_tiles(self, rank, tile_rows, world, stream=None):
+        want = (_pattern(self.H, self.W).to(torch.int64) + 5 * self.calls) % 251
+        for y0, y1 in tiles_of_rank(self.H, tile_rows, rank, world):
+            self.bound[self.H - y1:self.H - y0] = want[self.H - y1:self.H - y0].to(torch.uint8)
+        self.log.append(("render", self.calls, self.bound.data_ptr()))
+        self.calls += 1
+        if self.in_flight == 1:
+            self.joined_up_to = self.calls      # (one call at a time is joined into the caller's stream by itself)
+
+    def join(self, stream=None, keep_latest=0):
+        self.joined_up_to = max(self.joined_up_to, self.calls - keep_latest)
+        self.log.append(("join", keep_latest))
+
+
+def _pipeline_worker(rank, world, port, H, W, tile_rows, in_flight, n_frames, out_path):
+    from raytracer_amd.render import FramePipeline, TileGather
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    r = _StandInRenderer(H, W, tile_rows)
+    frames = [torch.zeros((H, W, 4), dtype=torch.uint8) for _ in range(in_flight)]
+    gather = TileGather(H, W, tile_rows, rank, world, "cpu", dist=dist, torch=torch)
+    got, order = [], []
+
+    def exchange(frame):
+        # the frame handed to the exchange must be one whose render call has been joined
+        call = [c for kind, c, ptr in (e for e in r.log if e[0] == "render") if ptr == frame.data_ptr()][-1]
+        assert call < r.joined_up_to, (call, r.joined_up_to)
+        order.append(call)
+        return gather(frame)
+
+    pipe = FramePipeline(r, frames, exchange, rank, world, tile_rows, on_frame=lambda i, f: got.append(f.clone()))
+    pipe.step()                                   # one call at a time first, as the benchmark does
+    pipe.set_in_flight(in_flight)
+    for _ in range(n_frames):
+        pipe.step()
+    assert len(pipe.waiting) == min(in_flight - 1, n_frames)
+    pipe.drain()
+    pipe.set_in_flight(1)
+    pipe.step()
+    assert order == list(range(n_frames + 2)) and pipe.done == n_frames + 2 and not pipe.waiting
+    if rank == 0:
+        np.save(out_path, torch.stack(got).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("H,W,tile_rows,world,in_flight,n_frames", [(70, 9, 8, 2, 3, 7), (37, 5, 5, 3, 2, 4), (64, 4, 16, 2, 4, 2),
+                                                                     (50, 7, 16, 2, 1, 3)])
+def test_frames_in_flight_are_each_exchanged_once_in_order(tmp_path, H, W, tile_rows, world, in_flight, n_frames):
+    """FramePipeline on gloo ranks with a stand-in renderer: with k calls in flight the exchange of frame i is
+    issued k - 1 steps after its render call and behind an rt_join that covers it; rank 0 ends up with every
+    frame, whole, in order -- also when fewer frames than lanes are rendered."""
+    out = str(tmp_path / "frames.npy")
+    mp.spawn(_pipeline_worker, args=(world, _free_port(), H, W, tile_rows, in_flight, n_frames, out), nprocs=world, join=True)
+    got = np.load(out)
+    assert got.shape[0] == n_frames + 2
+    for c in range(n_frames + 2):
+        want = ((_pattern(H, W).to(torch.int64) + 5 * c) % 251).to(torch.uint8).numpy()
+        assert np.array_equal(got[c], want), c
