@@ -1,6 +1,7 @@
 // Host driver: stands where the reference's main() does (raytracer.cpp:843-868).
 //
-//   rt_render <scene> [out.png] [-w W] [-h H] [-depth D] [-eps E] [-tile ROWS] [-gpus N] [-bvh] [-exact] [-stats]
+//   rt_render <scene> [out.png] [-w W] [-h H] [-depth D] [-eps E] [-tile ROWS] [-gpus N] [-frames F] [-inflight K]
+//             [-bvh] [-exact] [-stats]
 //
 // With no options it does what `./raytracer <scene> [out.png]` does: 1000 x 1000, eps 0.05,
 // depth 6, output.png (raytracer.cpp:847-862).  Parsing goes through the host loader
@@ -14,6 +15,11 @@
 // into the same rows of GPU 0's frame, no staging copy on either side.  One host thread per GPU,
 // one communicator per GPU from ncclCommInitAll.  The reference has no counterpart: it is one
 // thread on one CPU.
+//
+// -frames F -inflight K (with -gpus; -gpus 1 if that is not given): the frame is rendered F times with up to K
+// render calls in flight per GPU (RT_OPT_FRAMES_IN_FLIGHT), each into a frame buffer of its own; the exchange
+// of frame i is enqueued behind rt_join(stream, K - 1), beside the tracing of the frames after it.  The last
+// frame is the one written; -stats reports the rays of all F frames over the time of all of them.
 #include "rt_abi.h"
 #include "rt_host.h"
 
@@ -40,24 +46,16 @@ struct RankResult {
 
 // One GPU's share of an N-GPU frame.  Rank 0 ends up with the whole frame in `image`.
 void run_rank(int rank, int n_ranks, ncclComm_t comm, const rt_scene_desc* desc, int tile_rows, bool bvh, bool exact,
-              std::vector<uint8_t>* image, RankResult* out) {
+              int n_frames, int in_flight, std::vector<uint8_t>* image, RankResult* out) {
     auto fail = [&](const std::string& what) { out->rc = 1; out->error = "GPU " + std::to_string(rank) + ": " + what; };
     if (hipSetDevice(rank) != hipSuccess) return fail("hipSetDevice failed");
     const int W = desc->width, H = desc->height;
     const size_t frame_bytes = (size_t)W * H * 4;
     rt_ctx* ctx = nullptr;
-    void* frame = nullptr;
+    std::vector<void*> frames((size_t)in_flight, nullptr);      // one buffer per render call in flight
     hipStream_t stream = nullptr;
-    do {
-        if (rt_upload_scene(&ctx, desc)) { fail(rt_last_error()); break; }
-        if (exact && rt_set_option(ctx, RT_OPT_EXACT_ONLY, 1)) { fail(rt_last_error()); break; }
-        if (bvh && rt_set_option(ctx, RT_OPT_USE_BVH, 1)) { fail(rt_last_error()); break; }
-        if (hipMalloc(&frame, frame_bytes) != hipSuccess || hipMemset(frame, 0, frame_bytes) != hipSuccess) { fail("cannot allocate the frame"); break; }
-        if (rt_bind_frame(ctx, frame, frame_bytes)) { fail(rt_last_error()); break; }
-        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { fail("cannot create a stream"); break; }
-        const auto t0 = std::chrono::steady_clock::now();
-        if (rt_render_tiles(ctx, rank, tile_rows, n_ranks, stream)) { fail(rt_last_error()); break; }
-        // the exchange, enqueued behind the tiles on the same stream
+    // one frame's exchange, enqueued on `stream`: every tile's rows from its owner straight into GPU 0's frame
+    auto exchange = [&](void* frame) -> ncclResult_t {
         const int n_tiles = (H + tile_rows - 1) / tile_rows;
         ncclResult_t nr = ncclGroupStart();
         for (int k = 0; k < n_tiles && nr == ncclSuccess; k++) {
@@ -69,31 +67,64 @@ void run_rank(int rank, int n_ranks, ncclComm_t comm, const rt_scene_desc* desc,
             else if (rank == owner) nr = ncclSend((const char*)frame + off, bytes, ncclUint8, 0, comm, stream);
         }
         const ncclResult_t ne = ncclGroupEnd();
-        if (nr == ncclSuccess) nr = ne;
+        return nr == ncclSuccess ? ne : nr;
+    };
+    do {
+        if (rt_upload_scene(&ctx, desc)) { fail(rt_last_error()); break; }
+        if (exact && rt_set_option(ctx, RT_OPT_EXACT_ONLY, 1)) { fail(rt_last_error()); break; }
+        if (bvh && rt_set_option(ctx, RT_OPT_USE_BVH, 1)) { fail(rt_last_error()); break; }
+        if (in_flight > 1 && rt_set_option(ctx, RT_OPT_FRAMES_IN_FLIGHT, in_flight)) { fail(rt_last_error()); break; }
+        bool ok = true;
+        for (auto& f : frames)
+            ok = ok && hipMalloc(&f, frame_bytes) == hipSuccess && hipMemset(f, 0, frame_bytes) == hipSuccess;
+        if (!ok) { fail("cannot allocate the frame"); break; }
+        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { fail("cannot create a stream"); break; }
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<void*> waiting;                   // frames traced (or being traced) and not yet exchanged
+        ncclResult_t nr = ncclSuccess;
+        int rc = 0;
+        for (int i = 0; i < n_frames && !rc && nr == ncclSuccess; i++) {
+            void* frame = frames[(size_t)(i % in_flight)];
+            rc = rt_bind_frame(ctx, frame, frame_bytes);
+            if (!rc) rc = rt_render_tiles(ctx, rank, tile_rows, n_ranks, stream);
+            if (rc) break;
+            waiting.push_back(frame);
+            if ((int)waiting.size() == in_flight) {
+                // the oldest call's pixels, and only those, are waited for (a no-op with one call in flight,
+                // whose work is on `stream` already); its exchange runs beside the calls after it
+                rc = rt_join(ctx, stream, in_flight - 1);
+                if (!rc) nr = exchange(waiting.front());
+                waiting.erase(waiting.begin());
+            }
+        }
+        if (!rc) rc = rt_join(ctx, stream, 0);
+        for (size_t k = 0; k < waiting.size() && !rc && nr == ncclSuccess; k++) nr = exchange(waiting[k]);
+        if (rc) { fail(rt_last_error()); break; }
         if (nr != ncclSuccess) { fail(std::string("RCCL exchange: ") + ncclGetErrorString(nr)); break; }
         if (hipStreamSynchronize(stream) != hipSuccess) { fail("stream synchronisation failed"); break; }
         out->render_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (rt_get_stats(ctx, &out->stats)) { fail(rt_last_error()); break; }
         if (rank == 0) {
             image->resize(frame_bytes);
-            if (hipMemcpy(image->data(), frame, frame_bytes, hipMemcpyDeviceToHost) != hipSuccess) { fail("cannot copy the frame to the host"); break; }
+            void* last = frames[(size_t)((n_frames - 1) % in_flight)];
+            if (hipMemcpy(image->data(), last, frame_bytes, hipMemcpyDeviceToHost) != hipSuccess) { fail("cannot copy the frame to the host"); break; }
         }
     } while (false);
+    if (ctx) rt_free(ctx);                  // (waits for everything the context has enqueued)
     if (stream) (void)hipStreamDestroy(stream);
-    if (ctx) rt_free(ctx);
-    if (frame) (void)hipFree(frame);
+    for (void* f : frames) if (f) (void)hipFree(f);
 }
 
 }  // namespace
 
 int main(int argc, char** argv) {
     if (argc < 2) {
-        fprintf(stderr, "usage: %s <scene> [out.png] [-w W] [-h H] [-depth D] [-eps E] [-tile ROWS] [-gpus N] [-bvh] [-exact] [-stats]\n",
+        fprintf(stderr, "usage: %s <scene> [out.png] [-w W] [-h H] [-depth D] [-eps E] [-tile ROWS] [-gpus N] [-frames F] [-inflight K] [-bvh] [-exact] [-stats]\n",
                 argv[0]);
         return 2;
     }
     std::string scene = argv[1], out = "output.png";
-    int width = 1000, height = 1000, depth = -1, tile = 0, gpus = 0;
+    int width = 1000, height = 1000, depth = -1, tile = 0, gpus = 0, n_frames = 1, in_flight = 1;
     float eps = 0.f;
     bool bvh = false, exact = false, stats = false;
     int pos = 0;
@@ -109,6 +140,8 @@ int main(int argc, char** argv) {
         else if (a == "-eps") eps = (float)atof(need("-eps"));
         else if (a == "-tile") tile = atoi(need("-tile"));
         else if (a == "-gpus") gpus = atoi(need("-gpus"));
+        else if (a == "-frames") n_frames = atoi(need("-frames"));
+        else if (a == "-inflight") in_flight = atoi(need("-inflight"));
         else if (a == "-bvh") bvh = true;
         else if (a == "-exact") exact = true;
         else if (a == "-stats") stats = true;
@@ -116,6 +149,8 @@ int main(int argc, char** argv) {
         else { fprintf(stderr, "unexpected argument %s\n", a.c_str()); return 2; }
     }
     if (gpus < 0 || gpus > 64) { fprintf(stderr, "-gpus must be between 1 and 64\n"); return 2; }
+    if (n_frames < 1 || in_flight < 1 || in_flight > 4) { fprintf(stderr, "-frames must be at least 1, -inflight between 1 and 4\n"); return 2; }
+    if ((n_frames > 1 || in_flight > 1) && gpus == 0) gpus = 1;       // (the frame loop lives in the N-GPU path)
     printf("Ray Tracer!\n");
     auto now = []() { return std::chrono::steady_clock::now(); };
     auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(now() - t).count(); };
@@ -155,7 +190,7 @@ int main(int argc, char** argv) {
         {
             std::vector<std::thread> pool;
             for (int g = 0; g < gpus; g++)
-                pool.emplace_back(run_rank, g, gpus, comms[g], rth_desc(sc), rows, bvh, exact, &image, &results[g]);
+                pool.emplace_back(run_rank, g, gpus, comms[g], rth_desc(sc), rows, bvh, exact, n_frames, in_flight, &image, &results[g]);
             for (auto& th : pool) th.join();
         }
         const double wall = since(t0);         // upload, render, exchange and the copy to the host, all ranks
@@ -200,9 +235,9 @@ int main(int argc, char** argv) {
     printf("Scene render completed.\n");
     if (stats) {
         unsigned long long rays = st.rays_primary + st.rays_reflect + st.rays_shadow;
-        printf("{\"render_s\": %.6f, \"gpus\": %d, \"rays_primary\": %llu, \"rays_reflect\": %llu, \"rays_shadow\": %llu, \"hits\": %llu, "
+        printf("{\"render_s\": %.6f, \"frames\": %d, \"frames_in_flight\": %d, \"gpus\": %d, \"rays_primary\": %llu, \"rays_reflect\": %llu, \"rays_shadow\": %llu, \"hits\": %llu, "
                "\"Mrays_per_s\": %.3f, \"triangles\": %d, \"spheres\": %d}\n",
-               secs, gpus >= 1 ? gpus : 1, (unsigned long long)st.rays_primary, (unsigned long long)st.rays_reflect,
+               secs, n_frames, in_flight, gpus >= 1 ? gpus : 1, (unsigned long long)st.rays_primary, (unsigned long long)st.rays_reflect,
                (unsigned long long)st.rays_shadow, (unsigned long long)st.hits, rays / secs / 1e6, st.n_triangles, st.n_spheres);
     }
     printf("Writing to file...\n");

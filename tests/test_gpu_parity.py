@@ -431,3 +431,30 @@ def test_cli_driver_n_gpu_path_with_one_gpu(tmp_path):
     res = subprocess.run([exe, scene, str(multi), "-gpus", "63"] + common, capture_output=True, text=True)
     assert res.returncode == 1 and "visible" in res.stderr
 
+
+
+def test_cli_driver_frames_in_flight(tmp_path):
+    """`rt_render -frames F -inflight K`: the C++ driver's frame loop (a buffer per call in flight, rt_join before
+    each frame's exchange) must write the picture of a single render, and count F frames' rays."""
+    import json
+    import subprocess
+    exe = os.path.join(ROOT, "raytracer_amd", "rt_render")
+    assert os.path.exists(exe), "run `make cli`"
+    scene = os.path.join(ROOT, "scenes", "teapot.scene")
+    common = ["-w", "320", "-h", "181", "-depth", "5", "-stats"]
+    one = tmp_path / "one.png"
+    res = subprocess.run([exe, scene, str(one)] + common, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    rays1 = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{"render_s"')][0])
+    for frames, in_flight, extra in ((7, 3, []), (2, 4, ["-bvh"]), (5, 1, ["-tile", "8"]), (1, 2, [])):
+        out = tmp_path / f"f{frames}_{in_flight}.png"
+        res = subprocess.run([exe, scene, str(out), "-frames", str(frames), "-inflight", str(in_flight)] + extra + common,
+                             capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr
+        st = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{"render_s"')][0])
+        assert st["frames"] == frames and st["frames_in_flight"] == in_flight and st["gpus"] == 1
+        for k in ("rays_primary", "rays_reflect", "rays_shadow", "hits"):
+            assert st[k] == frames * rays1[k], (k, frames, in_flight)
+        assert np.array_equal(oracle_api.load_png(str(out)), oracle_api.load_png(str(one))), (frames, in_flight)
+    res = subprocess.run([exe, scene, str(one), "-inflight", "5"] + common, capture_output=True, text=True)
+    assert res.returncode == 2

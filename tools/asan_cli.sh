@@ -24,7 +24,7 @@ runs=0
 retried=0
 for sc in mixed_xf teapot campanile_teddy synthetic_small normals; do
   n=0
-  for opt in "" "-bvh" "-exact" "-tile 7" "-gpus 1 -tile 5"; do
+  for opt in "" "-bvh" "-exact" "-tile 7" "-gpus 1 -tile 5" "-frames 5 -inflight 3" "-frames 3 -inflight 4 -bvh"; do
     n=$((n + 1)); runs=$((runs + 1))
     timeout -k 10 120 asan_build/rt_render scenes/$sc.scene $out/asan.png -w 160 -h 90 -depth 3 $opt > $out/asan_out.log 2> $out/asan_err.log
     rc=$?
