@@ -447,6 +447,18 @@ k_bvh_trace(const DevScene* __restrict__ sc, BvhArgs B, TraceArgs A) {
 #pragma unroll 1
             for (int step = 0; step < RT_BVH_STEPS; step++) {
                 if (!active) break;
+#ifdef RT_BVH_UTIL
+                // diagnostic build: lane-steps worked (rt_stats.bvh_node_tests) against the lane-steps the wave spent on them
+                // (rt_stats.bvh_leaf_tests: 64 per step that any lane takes)
+                {
+                    const unsigned long long here = __ballot(true);
+                    n_node++;
+                    if (lane == (int)__builtin_ctzll(here)) n_leaf += 64;
+                    // ... and the steps in which some lanes stand at a leaf and others at a node (rt_stats.exact_tests, x 64)
+                    const unsigned long long at_leaf = __ballot(!need_group && cur < 0), at_node = __ballot(!need_group && cur >= 0);
+                    if (lane == (int)__builtin_ctzll(here) && at_leaf != 0ull && at_node != 0ull) n_exact += 64;
+                }
+#endif
                 if (need_group) {
                     if (n_staged > 0) break;            // the staged triangles belong to the group just left: drain first
                     if (prune) t_limit_identity = t_limit;
@@ -478,7 +490,9 @@ k_bvh_trace(const DevScene* __restrict__ sc, BvhArgs B, TraceArgs A) {
                     if (n_staged == RT_BVH_STAGE) break;
                     const int slot = -1 - cur;
                     const int axis = slot >= G->fax[2] ? 2 : (slot >= G->fax[1] ? 1 : 0);     // (fax[k]: where axis k's slots begin)
+#ifndef RT_BVH_UTIL
                     n_leaf++;
+#endif
                     float r_lo;
                     if (filter_keep1(filt + 16 * (size_t)slot, axis, px, py, pz, vx, vy, vz, G->q[MODE], robust, MODE, &r_lo) &&
                         !(r_lo > t_limit)) {
@@ -504,7 +518,9 @@ k_bvh_trace(const DevScene* __restrict__ sc, BvhArgs B, TraceArgs A) {
                         const bool h = r & !(tn > t_limit) & (c[k] != RT_BVH_NO_CHILD);
                         d[k] = h ? tn : INFINITY;
                         n_hit += h ? 1 : 0;
+#ifndef RT_BVH_UTIL
                         n_node += (c[k] != RT_BVH_NO_CHILD) ? 1 : 0;
+#endif
                     }
                     // nearest first: a five-exchange sorting network on (entry parameter, child); boxes not reached sort last
 #define RT_BVH_CSWAP(i, j) { const bool sw = d[j] < d[i]; const float td = sw ? d[j] : d[i]; d[j] = sw ? d[i] : d[j]; d[i] = td; \
@@ -552,7 +568,9 @@ k_bvh_trace(const DevScene* __restrict__ sc, BvhArgs B, TraceArgs A) {
                     const int slot = (int)my_stage[(--n_staged) * RT_BVH_BLOCK];
                     const TriExact& T = exact[slot];
                     const float t = tri_intersect_exact(T, pos, vec, eps);
+#ifndef RT_BVH_UTIL
                     n_exact++;
+#endif
                     if (MODE == 0) {
                         d3 world;
                         const float d = hit_metric(B.xforms + 48 * (size_t)G->xf, G->identity, pos, vec, t, &world);
