@@ -457,6 +457,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "one_frame_at_a_time_ms": one_at_a_time_ms,
+            "one_frame_at_a_time_value": rays_total / args.steps / (one_at_a_time_ms * 1e-3) / 1e6,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
