@@ -72,7 +72,7 @@ def parse():
                          "rehearse the N-rank flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-config5", action="store_true",
                     help="skip the roofline-stress leg (1,000,000 triangles + 64 spheres, 16 lights, depth 8)")
-    ap.add_argument("--frames-in-flight", type=int, default=3,
+    ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="render calls in flight in the timed region (RT_OPT_FRAMES_IN_FLIGHT, 1..4): frame i+1 is traced "
                          "beside the deep levels of frame i, each in a frame buffer of its own; 1 = one frame at a time")
     ap.add_argument("--dump-frame", default=None,

@@ -222,6 +222,8 @@ struct rt_ctx {
     // The lanes' streams, created once and kept until rt_free: which hardware queue a stream lands on is decided
     // when it is first used, and streams that share a queue do not overlap -- an arrangement that overlaps is kept.
     std::vector<hipStream_t> lane_streams;
+    std::vector<int> lane_stream_queue;   // per stream: the hardware queue it was found to sit on (numbered as found)
+    int lane_queues = 0;                  // how many different ones
     Lane* cur = nullptr;                  // the lane of the call being enqueued (null: the context's own resources)
     // `done` of the previous call in flight and the frame it wrote: a call that writes the same buffer runs its
     // folds behind it, so that pixels land in call order.  (Calls that write different buffers are not tied to each
@@ -444,6 +446,78 @@ void drain_spans(rt_ctx* c) {
 }
 
 // ---- RT_OPT_FRAMES_IN_FLIGHT > 1 ---------------------------------------------------------------------------
+
+// Spins for `ticks` of the constant 100 MHz clock (the probe below).
+__global__ void k_spin(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) {}
+}
+
+// The streams the lanes run on.  A process has few hardware queues (GPU_MAX_HW_QUEUES, 4 by default); the runtime
+// deals its streams onto them in an order of its own, and two streams on one queue run one after the other.  Lanes
+// whose streams share a queue with another lane's do not overlap at all (measured: two lanes on an unlucky deal gain
+// nothing, on four different queues 13 %), so the streams are sorted by queue here: twelve are created, and each is
+// timed against one stream of every queue found so far -- a 200 us spin kernel on both: side by side, or one after
+// the other.  Once per context, ~10 ms.
+int probe_lane_streams(rt_ctx* c) {
+    if (!c->lane_streams.empty()) return 0;
+    const int P = 12;
+    for (int i = 0; i < P; i++) {
+        hipStream_t s = nullptr;
+        HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        c->lane_streams.push_back(s);
+    }
+    c->lane_stream_queue.assign(P, -1);
+    c->lane_queues = 0;
+    HIP_TRY(hipDeviceSynchronize());
+    for (int i = 0; i < P; i++) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, c->lane_streams[i], 100);     // (a stream's first launch sets it up)
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    const long long ticks = 20000;                      // 200 us
+    auto pair_ms = [&](int a, int b, double* ms) -> int {
+        const auto t0 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, c->lane_streams[a], ticks);
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, c->lane_streams[b], ticks);
+        HIP_TRY(hipStreamSynchronize(c->lane_streams[a]));
+        HIP_TRY(hipStreamSynchronize(c->lane_streams[b]));
+        *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return 0;
+    };
+    std::vector<int> first_of;                          // a stream of every queue found so far
+    for (int i = 0; i < P; i++) {
+        for (size_t q = 0; q < first_of.size() && c->lane_stream_queue[i] < 0; q++) {
+            double ms = 0, again = 0;
+            int rc = pair_ms(first_of[q], i, &ms);
+            if (rc) return rc;
+            if (ms > 0.3) { rc = pair_ms(first_of[q], i, &again); if (rc) return rc; ms = std::min(ms, again); }   // (a hiccup of the host reads as "one after the other")
+            if (ms > 0.3) c->lane_stream_queue[i] = (int)q;        // 0.2 ms side by side, 0.4 ms one after the other
+        }
+        if (c->lane_stream_queue[i] < 0) {
+            c->lane_stream_queue[i] = (int)first_of.size();
+            first_of.push_back(i);
+        }
+    }
+    c->lane_queues = (int)first_of.size();
+    return 0;
+}
+
+// Lane `i` of `k`: its main stream on queue i (mod the number of queues found).  While there are two queues per lane
+// (two lanes on four queues) its side stream gets a queue of its own; otherwise the lane runs on its main stream
+// alone.  Lanes must not meet on a queue: with the side streams of three lanes on the one queue their main streams
+// leave over, three frames in flight take as long as one at a time (6.04 ms against 6.03), with every lane on a
+// queue of its own 5.16 ms.
+void deal_lane_streams(rt_ctx* c, int i, int k, hipStream_t* main_out, hipStream_t* side_out) {
+    const int Q = std::max(1, c->lane_queues);
+    auto stream_on = [&](int queue, int nth) {         // the nth stream found on that queue (the last one if there are fewer)
+        hipStream_t got = nullptr;
+        for (size_t s = 0; s < c->lane_streams.size(); s++)
+            if (c->lane_stream_queue[s] == queue) { got = c->lane_streams[s]; if (nth-- == 0) break; }
+        return got;
+    };
+    *main_out = stream_on(i % Q, i / Q);
+    *side_out = (2 * k <= Q) ? stream_on(k + i, 0) : *main_out;
+}
+
 void release_lane(Lane* L) {
     if (!L) return;
     for (auto e : L->ev_hit) (void)hipEventDestroy(e);
@@ -485,17 +559,15 @@ int ensure_lanes(rt_ctx* c) {
         HIP_TRY(hipDeviceSynchronize());
         drop_lanes(c);
     }
+    if ((int)c->lanes.size() < c->in_flight) {
+        rc = probe_lane_streams(c);
+        if (rc) return rc;
+    }
     while ((int)c->lanes.size() < c->in_flight) {
         Lane* L = new Lane;
         auto give_up = [&](int code, const std::string& msg) { release_lane(L); return fail(code, msg); };
         hipError_t e = hipSuccess;
-        const size_t at = 2 * c->lanes.size();
-        while (c->lane_streams.size() < at + 2 && e == hipSuccess) {
-            hipStream_t s = nullptr;
-            e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-            if (e == hipSuccess) c->lane_streams.push_back(s);
-        }
-        if (e == hipSuccess) { L->main = c->lane_streams[at]; L->side = c->lane_streams[at + 1]; }
+        deal_lane_streams(c, (int)c->lanes.size(), c->in_flight, &L->main, &L->side);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&L->in, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&L->done, hipEventDisableTiming);
         for (int k = 0; k < 2 * levels && e == hipSuccess; k++) {
@@ -740,8 +812,8 @@ int run_pass(rt_ctx* c, const Workspace& ws, PassDesc pd, int nrows, hipStream_t
     // timing on (RT_OPT_PROFILE) everything stays on one stream so that a kernel's duration is
     // its own.  Hit auxiliaries and occlusion bits alternate between two buffers by level
     // parity; k_hit of level k+2 waits for k_phong of level k before it overwrites them.
-    const bool overlap = side_work && c->overlap && !c->profile && levels > 1;
     hipStream_t side = c->cur ? c->cur->side : c->side_stream;
+    const bool overlap = side_work && c->overlap && !c->profile && levels > 1 && side != st;      // (a lane may have one stream only)
     hipEvent_t* ev_hit = c->cur ? c->cur->ev_hit.data() : c->ev_hit.data();
     hipEvent_t* ev_phong = c->cur ? c->cur->ev_phong.data() : c->ev_phong.data();
     hipStream_t sb = overlap ? side : st;
@@ -1777,8 +1849,10 @@ int rt_set_option(rt_ctx* c, int option, int64_t value) {
             HIP_TRY(hipSetDevice(c->device));
             int rc = sync_all(c);
             if (rc) return rc;
+            // (another number of lanes is another deal of the streams: the lanes are made anew at the next call;
+            // at 1 their workspaces go back to the device)
+            if ((int)value != c->in_flight) drop_lanes(c);
             c->in_flight = (int)value;
-            if (c->in_flight == 1) drop_lanes(c);       // (their workspaces go back to the device)
             return 0;
         }
         case RT_OPT_BOUNDING_TESTS: c->pretest = value ? 1 : 0; c->pretest_any = value == 1 ? 1 : 0; return 0;

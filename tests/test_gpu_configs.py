@@ -144,7 +144,7 @@ def test_two_rank_benchmark_flow_on_one_gpu():
         launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
                   "--gpus", "2", "--backend", "gloo"]
-        # three frames in flight per rank (the default): a frame is exchanged two steps after its render call
+        # four frames in flight per rank (the default): a frame is exchanged three steps after its render call
         two = subprocess.run(launch + ["--dump-frame", f2] + common, check=True, capture_output=True, text=True, timeout=300).stdout
         # ... and one frame at a time
         subprocess.run(launch + ["--dump-frame", f3, "--frames-in-flight", "1"] + common, check=True, capture_output=True,
@@ -153,7 +153,7 @@ def test_two_rank_benchmark_flow_on_one_gpu():
         b = json.loads([ln for ln in two.strip().splitlines() if ln.startswith("{")][-1])
         assert a["n_gpus"] == 1 and b["n_gpus"] == 2 and b["value"] > 0
         assert a["config"]["rays_per_frame"] == b["config"]["rays_per_frame"]
-        assert a["config"]["frames_in_flight"] == 3 and b["config"]["frames_in_flight"] == 3
+        assert a["config"]["frames_in_flight"] == 4 and b["config"]["frames_in_flight"] == 4
         # rank 0's frame after the exchange is the single-process frame, byte for byte
         want = np.load(f1)
         assert want.any()

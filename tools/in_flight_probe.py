@@ -32,7 +32,7 @@ def timed(fn, steps=12):
 for own_frames in (1,):
   r.bind_frame(frames[0])
   print('a frame buffer per call in flight' if own_frames else 'one frame buffer (folds in call order)')
-  for order in ((1, 3),):
+  for order in ((1, 2, 3, 4),):
     for bvh in (0, 1):
         r.set_option(abi.RT_OPT_USE_BVH, bvh)
         for world in worlds:
