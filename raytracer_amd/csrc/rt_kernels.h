@@ -196,6 +196,7 @@ k_primary(const DevScene* __restrict__ sc, PassDesc pd, int n_pix, RayQueue q,
 // ---------------------------------------------------------------------------
 struct TraceArgs {
     RayQueue rays;                       // MODE 0: the level's rays.  MODE 1: origins = hit points
+    int32_t beside_others;               // the launch runs beside the launches of other render calls (RT_OPT_FRAMES_IN_FLIGHT > 1)
     const uint32_t* n_items;             // MODE 0: number of rays; MODE 1: number of hits (shadow rays = hits * n_lights)
     unsigned long long* keys;            // MODE 0: per ray, atomicMin of (metric bits, object index)
     const int32_t* source_obj;           // MODE 1: object each hit lies on (excluded, raytracer.cpp:553)
@@ -1264,6 +1265,14 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
     // reflection rays differ a lot in cost, and the launch ends with its longest one)
     unsigned int per_wave = CONE == 1 ? RT_TASKS_PER_WAVE_BOUNDED : CONE == 2 ? RT_TASKS_PER_WAVE_SHADOW
                           : CONE == 4 ? RT_TASKS_PER_WAVE_ANY : 8u;
+    // A launch that shares the chip with the launches of other frames (TraceArgs::beside_others) need not keep the
+    // chip full to its end -- the others fill what it leaves idle -- and every part of the triangle range pays for
+    // loading the block's rays again: two tasks per wave then (four frames in flight: 5.01 -> 4.82 ms per frame; a
+    // frame on its own would take 6.6 ms instead of 6.0 that way).
+#ifndef RT_TASKS_PER_WAVE_BESIDE
+#define RT_TASKS_PER_WAVE_BESIDE 2
+#endif
+    if (CONE && A.beside_others && per_wave > RT_TASKS_PER_WAVE_BESIDE) per_wave = RT_TASKS_PER_WAVE_BESIDE;
     // A launch with few blocks of rays (a deep level, one rank's share of an N-GPU frame) gets its tasks by cutting
     // the triangle range, and every part loads the block's rays and builds their bundles again -- 40-60 % of
     // such a task.  Two tasks per wave then: 2.33 -> 2.13 ms for one rank's eighth of the 4K frame, and the
