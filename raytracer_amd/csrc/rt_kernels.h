@@ -1267,10 +1267,11 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                           : CONE == 4 ? RT_TASKS_PER_WAVE_ANY : 8u;
     // A launch that shares the chip with the launches of other frames (TraceArgs::beside_others) need not keep the
     // chip full to its end -- the others fill what it leaves idle -- and every part of the triangle range pays for
-    // loading the block's rays again: two tasks per wave then (four frames in flight: 5.01 -> 4.82 ms per frame; a
-    // frame on its own would take 6.6 ms instead of 6.0 that way).
+    // loading the block's rays again: three tasks per wave then, of half as many waves (the host halves the grid of
+    // such a launch).  Four frames in flight: 5.01 -> 4.70 ms per frame; a frame on its own would take 6.6 ms instead
+    // of 6.0 with so few tasks.
 #ifndef RT_TASKS_PER_WAVE_BESIDE
-#define RT_TASKS_PER_WAVE_BESIDE 2
+#define RT_TASKS_PER_WAVE_BESIDE 3
 #endif
     if (CONE && A.beside_others && per_wave > RT_TASKS_PER_WAVE_BESIDE) per_wave = RT_TASKS_PER_WAVE_BESIDE;
     // A launch with few blocks of rays (a deep level, one rank's share of an N-GPU frame) gets its tasks by cutting
