@@ -129,9 +129,10 @@ typedef enum rt_option {
                                  own with workspace i mod N, behind the work that was on the caller's stream at the
                                  time of the call, and is NOT joined back -- rt_join does that.  The short launches
                                  at the deep levels of one frame then run beside the large launches of the next
-                                 (4K teapot frame: 6.2 -> 5.5 ms per frame at 3; one rank's eighth of it: 1.96 ->
-                                 1.5 ms).  Pixels are identical; calls that write the same pixels land in call
-                                 order.  N workspaces are held.  RT_OPT_PROFILE and RT_OPT_WORK_COUNTERS renders
+                                 (4K teapot frame: 6.0 -> 4.7 ms per frame at 4; one rank's eighth of it: 2.0 ->
+                                 1.1 ms).  Pixels are identical; calls that write the same pixels land in call
+                                 order.  N workspaces are held, and every call in flight gets a hardware queue of
+                                 its own (found out with a ~10 ms probe the first time the option is used).  RT_OPT_PROFILE and RT_OPT_WORK_COUNTERS renders
                                  run as with 1.  Blocks until queued work has finished */
 } rt_option;
 
