@@ -385,8 +385,11 @@ struct BvhArgs {
     unsigned long long* tally;
 };
 
+#ifndef RT_BVH_MIN_WAVES
+#define RT_BVH_MIN_WAVES 1      // waves per SIMD the traversal is compiled for (a higher value caps its registers)
+#endif
 template <int MODE, bool WIDE = false>
-__global__ void __launch_bounds__(RT_BVH_BLOCK)
+__global__ void __launch_bounds__(RT_BVH_BLOCK, RT_BVH_MIN_WAVES)
 k_bvh_trace(const DevScene* __restrict__ sc, BvhArgs B, TraceArgs A) {
     const GroupBvh* __restrict__ bvh = B.bvh;
     const float* __restrict__ filt = B.filt;
