@@ -520,6 +520,16 @@ void deal_lane_streams(rt_ctx* c, int i, int k, hipStream_t* main_out, hipStream
     };
     *main_out = stream_on(i % Q, i / Q);
     *side_out = (2 * k <= Q) ? stream_on(k + i, 0) : *main_out;
+    // RT_LANE_REPORT in the environment: what the probe found and how the lanes were dealt (stderr)
+    if (std::getenv("RT_LANE_REPORT")) {
+        if (i == 0) {
+            fprintf(stderr, "lanes: %d hardware queue(s) found; streams by queue:", Q);
+            for (size_t s = 0; s < c->lane_streams.size(); s++) fprintf(stderr, " %d", c->lane_stream_queue[s]);
+            fprintf(stderr, "\n");
+        }
+        fprintf(stderr, "lanes: lane %d of %d: main stream on queue %d, %s\n", i, k, i % Q,
+                *side_out == *main_out ? "no side stream" : ("side stream on queue " + std::to_string(k + i)).c_str());
+    }
 }
 
 void release_lane(Lane* L) {
