@@ -180,3 +180,29 @@ def test_small_passes_in_flight():
     for k in COUNTS:
         assert st[k] == 5 * st1[k], k
     r.close()
+
+
+def test_no_two_lanes_share_a_hardware_queue(tmp_path):
+    """RT_LANE_REPORT: the queue probe must find the process's hardware queues (several: HIP's default is 4), and
+    the lanes' main streams must sit on different ones whenever there are at least as many queues as lanes; two
+    lanes on four queues also get a side stream each, on the two queues left."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "raytracer_amd", "rt_render")
+    assert os.path.exists(exe), "run `make cli`"
+    for k in (2, 3, 4):
+        env = dict(os.environ, RT_LANE_REPORT="1")
+        res = subprocess.run([exe, os.path.join(ROOT, "scenes", "mixed_xf.scene"), str(tmp_path / "o.png"), "-w", "160", "-h", "120",
+                              "-depth", "3", "-frames", "6", "-inflight", str(k)], capture_output=True, text=True, env=env)
+        assert res.returncode == 0, res.stderr
+        found = int(re.search(r"lanes: (\d+) hardware queue", res.stderr).group(1))
+        assert found >= 2, res.stderr
+        mains = [int(q) for q in re.findall(r"main stream on queue (\d+)", res.stderr)]
+        sides = [int(q) for q in re.findall(r"side stream on queue (\d+)", res.stderr)]
+        assert len(mains) == k
+        if found >= k:
+            assert len(set(mains)) == k, res.stderr
+        if found >= 2 * k:
+            assert len(sides) == k and len(set(mains + sides)) == 2 * k, res.stderr
+        else:
+            assert not sides, res.stderr
