@@ -463,8 +463,17 @@ __global__ void k_spin(long long ticks) {
 // nothing, on four different queues 13 %), so the streams are sorted by queue here: twelve are created, and each is
 // timed against one stream of every queue found so far -- a 200 us spin kernel on both: side by side, or one after
 // the other.  Once per context, ~10 ms.
+int probe_lane_streams_once(rt_ctx* c);
 int probe_lane_streams(rt_ctx* c) {
     if (!c->lane_streams.empty()) return 0;
+    const int rc = probe_lane_streams_once(c);
+    if (rc) {               // (nothing half-made is kept: the next call starts over)
+        for (auto st : c->lane_streams) (void)hipStreamDestroy(st);
+        c->lane_streams.clear(); c->lane_stream_queue.clear(); c->lane_queues = 0;
+    }
+    return rc;
+}
+int probe_lane_streams_once(rt_ctx* c) {
     const int P = 12;
     for (int i = 0; i < P; i++) {
         hipStream_t s = nullptr;
@@ -519,7 +528,9 @@ void deal_lane_streams(rt_ctx* c, int i, int k, hipStream_t* main_out, hipStream
         return got;
     };
     *main_out = stream_on(i % Q, i / Q);
+    if (!*main_out) *main_out = c->lane_streams[(size_t)i % c->lane_streams.size()];      // (cannot happen: every queue found holds a stream)
     *side_out = (2 * k <= Q) ? stream_on(k + i, 0) : *main_out;
+    if (!*side_out) *side_out = *main_out;
     // RT_LANE_REPORT in the environment: what the probe found and how the lanes were dealt (stderr)
     if (std::getenv("RT_LANE_REPORT")) {
         if (i == 0) {
