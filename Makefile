@@ -37,6 +37,9 @@ clean:
 	rm -rf asan_build
 
 # instruction-rate microbenchmarks behind the numbers quoted for the filter kernel
+stream_queue_probe:
+	$(HIPCC) --offload-arch=gfx950 -O2 -o tools/stream_queue_probe tools/stream_queue_probe.hip
+
 microbench:
 	for b in microbench microbench2 microbench3 microbench4 microbench5; do $(HIPCC) --offload-arch=gfx950 -O3 -o tools/$$b tools/$$b.hip || exit 1; done
 
@@ -52,7 +55,7 @@ asan:
 	$(ASANXX) -O1 -g -std=c++17 -pthread -fsanitize=address -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include -o asan_build/rt_render $(PKG)/host/rt_cli.cpp \
 	  -Lasan_build -lrt_host -lraytracer_amd -L/opt/rocm/lib -lamdhip64 -lrccl -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 
-.PHONY: all host hip cli oracle clean microbench asan
+.PHONY: all host hip cli oracle clean microbench asan stream_queue_probe
 
 # A build of the device library with extra flags under variants/ (A/B measurements, diagnostic builds):
 #   make variant NAME=phase FLAGS=-DRT_PHASE_CLOCK  ->  variants/libraytracer_amd_phase.so  (RAYTRACER_AMD_LIB selects it)
