@@ -30,6 +30,11 @@ import subprocess
 import sys
 import time
 
+# Four render calls in flight run on four hardware queues, and the stream this program itself enqueues on (joins,
+# the exchange) should not sit on one of them: what it is given would queue up behind a whole frame of that lane.
+# HIP deals a process 4 queues unless told otherwise, and reads this when it starts up -- before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

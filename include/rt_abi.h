@@ -132,7 +132,10 @@ typedef enum rt_option {
                                  (4K teapot frame: 6.0 -> 4.7 ms per frame at 4; one rank's eighth of it: 2.0 ->
                                  1.1 ms).  Pixels are identical; calls that write the same pixels land in call
                                  order.  N workspaces are held, and every call in flight gets a hardware queue of
-                                 its own (found out with a ~10 ms probe the first time the option is used).  RT_OPT_PROFILE and RT_OPT_WORK_COUNTERS renders
+                                 its own (found out with a ~10 ms probe the first time the option is used); the
+                                 caller's stream shares one unless the process has more queues than calls in
+                                 flight (GPU_MAX_HW_QUEUES, 4 by default, read by HIP at its first call) -- what
+                                 is enqueued on it then waits behind that call's kernels.  RT_OPT_PROFILE and RT_OPT_WORK_COUNTERS renders
                                  run as with 1.  Blocks until queued work has finished */
 } rt_option;
 

@@ -228,6 +228,7 @@ struct rt_ctx {
     std::vector<hipStream_t> lane_streams;
     std::vector<int> lane_stream_queue;   // per stream: the hardware queue it was found to sit on (numbered as found)
     int lane_queues = 0;                  // how many different ones
+    int caller_queue = -1;                // the queue the caller's stream sat on when the lanes were made (-1: not known)
     Lane* cur = nullptr;                  // the lane of the call being enqueued (null: the context's own resources)
     // `done` of the previous call in flight and the frame it wrote: a call that writes the same buffer runs its
     // folds behind it, so that pixels land in call order.  (Calls that write different buffers are not tied to each
@@ -514,6 +515,31 @@ int probe_lane_streams_once(rt_ctx* c) {
     return 0;
 }
 
+// Which of the queues found does `st` (the caller's stream) sit on?  The same test, against one stream of each.
+int probe_caller_queue(rt_ctx* c, hipStream_t st) {
+    c->caller_queue = -1;
+    const long long ticks = 20000;
+    HIP_TRY(hipDeviceSynchronize());
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, st, 100);
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int q = 0; q < c->lane_queues && c->caller_queue < 0; q++) {
+        int rep_stream = -1;
+        for (size_t s = 0; s < c->lane_streams.size() && rep_stream < 0; s++) if (c->lane_stream_queue[s] == q) rep_stream = (int)s;
+        if (rep_stream < 0) continue;
+        double best = 1e9;
+        for (int attempt = 0; attempt < 2 && best > 0.3; attempt++) {
+            const auto t0 = std::chrono::steady_clock::now();
+            hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, c->lane_streams[(size_t)rep_stream], ticks);
+            hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, st, ticks);
+            HIP_TRY(hipStreamSynchronize(c->lane_streams[(size_t)rep_stream]));
+            HIP_TRY(hipStreamSynchronize(st));
+            best = std::min(best, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        }
+        if (best > 0.3) c->caller_queue = q;
+    }
+    return 0;
+}
+
 // Lane `i` of `k`: its main stream on queue i (mod the number of queues found).  While there are two queues per lane
 // (two lanes on four queues) its side stream gets a queue of its own; otherwise the lane runs on its main stream
 // alone.  Lanes must not meet on a queue: with the side streams of three lanes on the one queue their main streams
@@ -521,25 +547,33 @@ int probe_lane_streams_once(rt_ctx* c) {
 // queue of its own 5.16 ms.
 void deal_lane_streams(rt_ctx* c, int i, int k, hipStream_t* main_out, hipStream_t* side_out) {
     const int Q = std::max(1, c->lane_queues);
+    // the queues in the order they are given out: the caller's stream's own queue last (what the caller's stream is
+    // given -- rt_join's waits, the events that order a call behind the caller's work, an exchange -- queues up
+    // behind everything a lane on that queue holds)
+    std::vector<int> order;
+    for (int q = 0; q < Q; q++) if (q != c->caller_queue) order.push_back(q);
+    if (c->caller_queue >= 0 && c->caller_queue < Q) order.push_back(c->caller_queue);
     auto stream_on = [&](int queue, int nth) {         // the nth stream found on that queue (the last one if there are fewer)
         hipStream_t got = nullptr;
         for (size_t s = 0; s < c->lane_streams.size(); s++)
             if (c->lane_stream_queue[s] == queue) { got = c->lane_streams[s]; if (nth-- == 0) break; }
         return got;
     };
-    *main_out = stream_on(i % Q, i / Q);
+    const int main_queue = order[(size_t)(i % Q)];
+    *main_out = stream_on(main_queue, i / Q);
     if (!*main_out) *main_out = c->lane_streams[(size_t)i % c->lane_streams.size()];      // (cannot happen: every queue found holds a stream)
-    *side_out = (2 * k <= Q) ? stream_on(k + i, 0) : *main_out;
+    const int side_queue = (2 * k <= Q) ? order[(size_t)(k + i)] : -1;
+    *side_out = side_queue >= 0 ? stream_on(side_queue, 0) : *main_out;
     if (!*side_out) *side_out = *main_out;
     // RT_LANE_REPORT in the environment: what the probe found and how the lanes were dealt (stderr)
     if (std::getenv("RT_LANE_REPORT")) {
         if (i == 0) {
-            fprintf(stderr, "lanes: %d hardware queue(s) found; streams by queue:", Q);
+            fprintf(stderr, "lanes: %d hardware queue(s) found, the caller's stream on queue %d; streams by queue:", Q, c->caller_queue);
             for (size_t s = 0; s < c->lane_streams.size(); s++) fprintf(stderr, " %d", c->lane_stream_queue[s]);
             fprintf(stderr, "\n");
         }
-        fprintf(stderr, "lanes: lane %d of %d: main stream on queue %d, %s\n", i, k, i % Q,
-                *side_out == *main_out ? "no side stream" : ("side stream on queue " + std::to_string(k + i)).c_str());
+        fprintf(stderr, "lanes: lane %d of %d: main stream on queue %d, %s\n", i, k, main_queue,
+                *side_out == *main_out ? "no side stream" : ("side stream on queue " + std::to_string(side_queue)).c_str());
     }
 }
 
@@ -573,7 +607,7 @@ void drop_lanes(rt_ctx* c) {
 
 // `in_flight` lanes, each with a workspace for the current options, streams, events and (when the LBVH is built)
 // traversal strips.  A lane is only added to the context when all of it exists.
-int ensure_lanes(rt_ctx* c) {
+int ensure_lanes(rt_ctx* c, hipStream_t caller) {
     size_t want = 0;
     int rc = pass_size(c, &want);
     if (rc) return rc;
@@ -587,6 +621,10 @@ int ensure_lanes(rt_ctx* c) {
     if ((int)c->lanes.size() < c->in_flight) {
         rc = probe_lane_streams(c);
         if (rc) return rc;
+        if (c->lanes.empty()) {             // (one deal for all lanes of a set)
+            rc = probe_caller_queue(c, caller);
+            if (rc) return rc;
+        }
     }
     while ((int)c->lanes.size() < c->in_flight) {
         Lane* L = new Lane;
@@ -938,12 +976,20 @@ int render_rows(rt_ctx* c, int y_start, int tile_rows, int stride_rows, int n_ti
         }
         return 0;
     }
-    int rc = ensure_lanes(c);
+    int rc = ensure_lanes(c, st);
     if (rc) return rc;
     Lane* L = c->lanes[c->seq % (unsigned long long)c->in_flight];
-    // behind what the caller's stream holds now (and, by stream order, behind the lane's previous call)
-    HIP_TRY(hipEventRecord(L->in, st));
-    HIP_TRY(hipStreamWaitEvent(L->main, L->in, 0));
+    // Behind what the caller's stream holds now (and, by stream order, behind the lane's previous call) -- when it
+    // holds anything.  The caller's stream shares its hardware queue with one of the lanes, and an event recorded on
+    // it queues up behind everything that lane has been given: with an idle caller's stream asked to mark every call,
+    // calls waited for marks stuck behind a whole frame of another lane (20 frames took 100 ms instead of 93
+    // whenever the first of them did not go to that lane).
+    const hipError_t busy = hipStreamQuery(st);
+    (void)hipGetLastError();                   // (hipErrorNotReady is an answer, not a failure to report later)
+    if (busy != hipSuccess) {
+        HIP_TRY(hipEventRecord(L->in, st));
+        HIP_TRY(hipStreamWaitEvent(L->main, L->in, 0));
+    }
     const int rows_per_pass = (int)(L->ws.cap / W);
     c->last_stream = st;
     c->cur = L;

@@ -151,6 +151,9 @@ int main(int argc, char** argv) {
     if (gpus < 0 || gpus > 64) { fprintf(stderr, "-gpus must be between 1 and 64\n"); return 2; }
     if (n_frames < 1 || in_flight < 1 || in_flight > 4) { fprintf(stderr, "-frames must be at least 1, -inflight between 1 and 4\n"); return 2; }
     if ((n_frames > 1 || in_flight > 1) && gpus == 0) gpus = 1;       // (the frame loop lives in the N-GPU path)
+    // Calls in flight run on a hardware queue each, and the stream the exchange is enqueued on should have one of its
+    // own; HIP deals a process 4 unless told otherwise, and reads this at its first call.
+    if (in_flight > 1) setenv("GPU_MAX_HW_QUEUES", "8", 0);
     printf("Ray Tracer!\n");
     auto now = []() { return std::chrono::steady_clock::now(); };
     auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(now() - t).count(); };

@@ -241,7 +241,9 @@ class FramePipeline:
             return
         self.waiting.append(frame)
         if len(self.waiting) == k:
-            self.r.join(self.stream, k - 1)
+            # (one rank and nobody to hand the frame to: nothing to order on the caller's stream until drain())
+            if self.world > 1 or self.on_frame is not None:
+                self.r.join(self.stream, k - 1)
             self._hand_on(self.waiting.pop(0))
 
     def drain(self):
