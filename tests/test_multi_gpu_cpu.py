@@ -171,3 +171,27 @@ def test_frames_in_flight_are_each_exchanged_once_in_order(tmp_path, H, W, tile_
     for c in range(n_frames + 2):
         want = ((_pattern(H, W).to(torch.int64) + 5 * c) % 251).to(torch.uint8).numpy()
         assert np.array_equal(got[c], want), c
+
+
+def test_one_rank_without_a_consumer_joins_only_at_the_end():
+    """One rank and nobody to hand frames to: FramePipeline must put nothing on the caller's stream per frame (what
+    is enqueued there waits behind a lane's kernels when the two share a hardware queue) -- one join, in drain().
+    With a consumer the per-frame joins are back."""
+    from raytracer_amd.render import FramePipeline
+    H, W, T = 32, 4, 8
+    for consumer in (False, True):
+        r = _StandInRenderer(H, W, T)
+        frames = [torch.zeros((H, W, 4), dtype=torch.uint8) for _ in range(4)]
+        seen = []
+        pipe = FramePipeline(r, frames, lambda f: f, 0, 1, T, on_frame=(lambda i, f: seen.append(i)) if consumer else None)
+        pipe.set_in_flight(4)
+        for _ in range(9):
+            pipe.step()
+        joins_before_drain = [e for e in r.log if e[0] == "join"]
+        pipe.drain()
+        joins = [e for e in r.log if e[0] == "join"]
+        assert pipe.done == 9 and not pipe.waiting
+        if consumer:
+            assert joins_before_drain == [("join", 3)] * 6 and joins[-1] == ("join", 0) and seen == list(range(9))
+        else:
+            assert joins_before_drain == [] and joins == [("join", 0)]
