@@ -30,10 +30,12 @@ import subprocess
 import sys
 import time
 
-# Four render calls in flight run on four hardware queues, and the stream this program itself enqueues on (joins,
-# the exchange) should not sit on one of them: what it is given would queue up behind a whole frame of that lane.
-# HIP deals a process 4 queues unless told otherwise, and reads this when it starts up -- before torch is imported.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Four render calls in flight want two hardware queues each (the two streams of a pass), and the stream this program
+# itself enqueues on (joins, the exchange) should not sit on one of them: what it is given would queue up behind a
+# whole frame of that lane.  HIP deals a process 4 queues unless told otherwise, and reads this when it starts up --
+# before torch is imported.  (4 queues: 4.7-5.1 ms per frame depending on which lane the caller's stream shares a
+# queue with; 8: 4.6-5.0; 16: 4.61-4.63.)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
