@@ -7,6 +7,16 @@ every rank traces its interleaved 16-row scanline tiles through the C ABI
 (rt_render_tiles) and the tiles are gathered to rank 0.  Inputs (the uploaded scene) are
 resident in HBM before the timed region.  Rank 0 prints one JSON line.
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks
+itself: a fresh `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>`
+child, before this process has touched the GPU, whose output and exit status become this
+program's.  Started by torch.distributed.run (WORLD_SIZE set), WORLD_SIZE must equal --gpus.
+
+Legs that run at every world size, through the same tile / exchange path as the headline:
+  config4   campanile + teddy, 7680 x 4320, depth 6: brute force and through the LBVH
+  config5   1,000,000 triangles + 64 spheres, 16 lights, depth 8, 7680 x 4320 through the LBVH
+            (and, on rank 0's GPU alone, the plain FP32 scan of a 512 x 288 frame of it)
+
   roofline      the dominant kernel, the FP32 filter scan k_filter, in the form in which every
                 ray x triangle pair takes the FP32 triangle test (a leg of K frames with
                 RT_OPT_BOUNDING_TESTS = 0 after the timed region):
@@ -79,6 +89,13 @@ def parse():
                          "rehearse the N-rank flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-config5", action="store_true",
                     help="skip the roofline-stress leg (1,000,000 triangles + 64 spheres, 16 lights, depth 8)")
+    ap.add_argument("--no-config4", action="store_true",
+                    help="skip the campanile + teddy 8K leg (brute force and LBVH)")
+    ap.add_argument("--config-size", default="7680x4320",
+                    help="frame size of the config4 / config5 legs (tests shrink it; the configurations are quoted at 7680x4320)")
+    ap.add_argument("--exchange", default="tiles", choices=["tiles", "packed"],
+                    help="end-of-frame exchange for N > 1: one point-to-point transfer per tile straight into rank 0's "
+                         "frame rows (tiles), or one per peer through a packed buffer (packed); same bytes either way")
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="render calls in flight in the timed region (RT_OPT_FRAMES_IN_FLIGHT, 1..4): frame i+1 is traced "
                          "beside the deep levels of frame i, each in a frame buffer of its own; 1 = one frame at a time")
@@ -87,6 +104,141 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true",
                     help="one stream: no overlap of a level's shadow launches with the next level's nearest-hit launches")
     return ap.parse_args()
+
+
+def start_ranks_if_asked(args):
+    """`--gpus N` without a launcher: this process becomes the parent of a torch.distributed.run job of N
+    ranks running this same file with the same arguments.  Must be called before anything initialises the
+    GPU (a child process, never an exec of a process that holds the device)."""
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ws}: start it as `python bench.py --gpus N` or "
+                     f"with --nproc-per-node equal to --gpus")
+        return
+    if args.gpus <= 1:
+        return
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd).returncode)
+
+
+class Job:
+    """This process's place in the N-rank job: rank, device, collective backend and the small reductions."""
+
+    def __init__(self, args, torch, dist):
+        self.torch, self.dist, self.backend = torch, dist, args.backend
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        n_dev = torch.cuda.device_count()
+        if self.world > 1:
+            if args.backend == "nccl" and n_dev < self.world:
+                sys.exit(f"bench.py: {self.world} ranks over RCCL need {self.world} GPUs, {n_dev} visible "
+                         f"(--backend gloo rehearses the N-rank flow with ranks sharing a GPU)")
+            local_rank %= max(1, n_dev)      # (more ranks than devices: a rehearsal on a smaller box)
+            torch.cuda.set_device(local_rank)
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(0)
+        self.dev = torch.device("cuda", torch.cuda.current_device())
+        self.coll_dev = self.dev if args.backend == "nccl" else torch.device("cpu")      # where the small reductions live
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.host_staging = args.backend != "nccl"
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def reduce(self, values, op):
+        """max / sum over ranks of a list of numbers (float64)."""
+        if self.world == 1:
+            return [float(v) for v in values]
+        t = self.torch.tensor([float(v) for v in values], dtype=self.torch.float64, device=self.coll_dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.SUM)
+        return [float(v) for v in t.tolist()]
+
+    def share_text(self, text):
+        """rank 0's string on every rank."""
+        if self.world == 1:
+            return text
+        box = [text]
+        self.dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+
+def run_frames(job, args, scene, steps, in_flight, options=()):
+    """K frames of `scene` on this job's ranks through the headline's path: interleaved tiles per rank
+    (rt_render_tiles), `in_flight` render calls in flight, every frame exchanged to rank 0; timed between
+    barriers, the maximum over ranks.  Returns the figures and rank-local statistics."""
+    from raytracer_amd import abi
+    from raytracer_amd.render import FramePipeline, Renderer, make_exchange
+    torch = job.torch
+    t0 = time.perf_counter()
+    r = Renderer(scene)
+    upload_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for opt, val in options:
+        r.set_option(opt, val)
+    options_s = time.perf_counter() - t0
+    H, W = scene.height, scene.width
+    frames = [torch.zeros((H, W, 4), dtype=torch.uint8, device=job.dev) for _ in range(in_flight)]
+    exchange = make_exchange(args.exchange, H, W, args.tile_rows, job.rank, job.world, job.dev, dist=job.dist, torch=torch,
+                             host_staging=job.host_staging)
+    pipe = FramePipeline(r, frames, exchange, job.rank, job.world, args.tile_rows, job.stream)
+
+    def fence():
+        pipe.drain()
+        job.barrier()
+
+    pipe.set_in_flight(in_flight)
+    for _ in range(max(1, in_flight)):          # (every lane's workspace is in place)
+        pipe.step()
+    fence()
+    r.reset_stats()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipe.step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    st = r.stats()
+    rays = st["rays_primary"] + st["rays_reflect"] + st["rays_shadow"]
+    elapsed, = job.reduce([elapsed], "max")
+    rays_total, = job.reduce([rays], "sum")
+    out = {"frame": f"{W}x{H}", "depth": scene.desc.max_depth, "steps": steps, "frames_in_flight": in_flight,
+           "ms_per_step": elapsed / steps * 1e3, "rays_per_frame": rays_total / steps,
+           "Mrays_per_s": rays_total / elapsed / 1e6, "upload_s": upload_s, "options_s": options_s,
+           "triangles": st["n_triangles"], "spheres": st["n_spheres"], "lights": scene.desc.n_lights,
+           "flagged_rays": st["flagged_rays"], "filter_form": st["filter_form"]}
+    if st["bvh_node_tests"]:
+        out.update({"box_tests_per_ray": st["bvh_node_tests"] / max(1, rays), "leaf_tests_per_ray": st["bvh_leaf_tests"] / max(1, rays),
+                    "exact_retests_per_ray": st["exact_tests"] / max(1, rays)})
+    r.close()
+    del frames
+    torch.cuda.empty_cache()
+    return out
+
+
+def config4_leg(job, args, steps, in_flight):
+    """campanile + teddy (23,243 triangles, 48 of them zero-area: the reference shadows every point, the frame is
+    ambient light only), 7680 x 4320, depth 6, split over this job's ranks by interleaved tiles: brute force and
+    through the LBVH."""
+    from raytracer_amd import Scene, abi
+    cw, ch = (int(v) for v in args.config_size.split("x"))
+    sc = Scene.load(os.path.join(ROOT, "scenes", "campanile_teddy.scene"), cw, ch, 6)
+    return {"scene": "campanile_teddy.scene", "n_gpus": job.world,
+            "brute_force": run_frames(job, args, sc, steps, in_flight),
+            "lbvh": run_frames(job, args, sc, steps, in_flight, options=[(abi.RT_OPT_USE_BVH, 1)])}
 
 
 def cpu_baseline(args, gpu_rays_fn):
@@ -122,78 +274,75 @@ def cpu_baseline(args, gpu_rays_fn):
     return out
 
 
-def config5_leg(steps):
+def config5_leg(job, args, steps, in_flight):
     """The roofline-stress configuration: a tessellated height field of 1,000,000 triangles + 64 reflective
     spheres (every 4th an ellipsoid), 16 lights, depth 8 (tools/make_synthetic.py writes it as .scene / .obj
-    text, no random numbers).  Two measurements on this GPU:
-      plain_scan  a 512 x 288 frame with RT_OPT_BOUNDING_TESTS = 0: every ray x triangle pair takes the FP32
-                  triangle test (the scene takes the filter's per-test margin form) -- the FP32 roofline
-                  fraction of the brute-force scan on a mesh 158 times the teapot's size;
-      lbvh_8k     the full 7680 x 4320 frame through the GPU-built LBVH (brute force at that size is 3 x 10^14 pairs)."""
+    text, no random numbers).
+      plain_scan  on rank 0's GPU alone: a 512 x 288 frame with RT_OPT_BOUNDING_TESTS = 0, every ray x triangle
+                  pair takes the FP32 triangle test (the scene takes the filter's per-test margin form) -- the
+                  FP32 roofline fraction of the brute-force scan on a mesh 158 times the teapot's size;
+      lbvh_8k     the full 7680 x 4320 frame through the GPU-built LBVH, split over this job's ranks by interleaved
+                  tiles and exchanged to rank 0 like the headline's frames (brute force at that size is 3 x 10^14 pairs)."""
+    import shutil
     import tempfile
     from raytracer_amd import Scene, abi
     from raytracer_amd.render import Renderer
-    out = {}
-    with tempfile.TemporaryDirectory() as tmp:
+    out = {"n_gpus": job.world}
+    tmp = None
+    if job.rank == 0:
+        tmp = tempfile.mkdtemp(prefix="rt_config5_")
         t0 = time.perf_counter()
         subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synthetic.py"), tmp], check=True, stdout=subprocess.DEVNULL)
-        path = os.path.join(tmp, "synthetic.scene")
-        t1 = time.perf_counter()
-        sc = Scene.load(path, 512, 288, 8)
-        t2 = time.perf_counter()
-        r = Renderer(sc)
-        t3 = time.perf_counter()
-        out["host"] = {"generate_text_s": t1 - t0, "parse_s": t2 - t1, "upload_s": t3 - t2}
-        r.set_option(abi.RT_OPT_BOUNDING_TESTS, 0)
-        r.set_option(abi.RT_OPT_PROFILE, 1)
-        r.render_frame()
-        r.reset_stats()
-        tp = time.perf_counter()
-        r.render_frame()
-        st = r.stats()
-        wall = time.perf_counter() - tp
-        n_tri, n_sph = st["n_triangles"], st["n_spheres"]
-        tri_share = n_tri / (n_tri + n_sph)
-        ms = st["closest_ms"] + st["anyhit_ms"]
-        tests = (st["closest_tests"] + st["anyhit_tests"]) * tri_share
-        rays = st["rays_primary"] + st["rays_reflect"] + st["rays_shadow"]
-        out["plain_scan"] = {"frame": "512x288", "triangles": n_tri, "spheres": n_sph, "filter_form": st["filter_form"],
-                             "rays": rays, "ray_triangle_tests": tests, "filter_kernels_ms": ms, "frame_ms": wall * 1e3,
-                             "achieved_tflops": tests * FLOP_TRI / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
-                             "frac_of_peak": tests * FLOP_TRI / (ms * 1e-3) / PEAK_FP32_VALU if ms > 0 else 0.0,
-                             "reference_precision_kernels_ms": st["exact_ms"],
-                             "note": "42 FLOP per ray x triangle test; reference_precision_kernels_ms holds the listed pairs "
-                                     "and the spheres (FP32 pre-test, survivors in the reference's arithmetic)"}
-        # the same small frame with the default bounding tests, and through the LBVH
-        r.set_option(abi.RT_OPT_BOUNDING_TESTS, 1)
-        r.set_option(abi.RT_OPT_PROFILE, 0)
-        r.render_frame()
-        r.reset_stats()
-        tp = time.perf_counter()
-        r.render_frame()
-        r.stats()
-        out["bounded_scan"] = {"frame": "512x288", "frame_ms": (time.perf_counter() - tp) * 1e3}
-        r.close()
-        sc8 = Scene.load(path, 7680, 4320, 8)
-        r = Renderer(sc8)
-        tb = time.perf_counter()
-        r.set_option(abi.RT_OPT_USE_BVH, 1)
-        build_s = time.perf_counter() - tb
-        r.render_frame()
-        r.reset_stats()
-        tp = time.perf_counter()
-        for _ in range(steps):
+        out["host"] = {"generate_text_s": time.perf_counter() - t0}
+    tmp = job.share_text(tmp)                     # (one node: every rank reads rank 0's files)
+    path = os.path.join(tmp, "synthetic.scene")
+    try:
+        if job.rank == 0:
+            t1 = time.perf_counter()
+            sc = Scene.load(path, 512, 288, 8)
+            t2 = time.perf_counter()
+            r = Renderer(sc)
+            t3 = time.perf_counter()
+            out["host"].update({"parse_s": t2 - t1, "upload_s": t3 - t2})
+            r.set_option(abi.RT_OPT_BOUNDING_TESTS, 0)
+            r.set_option(abi.RT_OPT_PROFILE, 1)
             r.render_frame()
-        sb = r.stats()
-        wall = (time.perf_counter() - tp) / steps
-        rays = (sb["rays_primary"] + sb["rays_reflect"] + sb["rays_shadow"]) / steps
-        out["lbvh_8k"] = {"frame": "7680x4320", "steps": steps, "ms_per_step": wall * 1e3, "rays_per_frame": rays,
-                          "Mrays_per_s": rays / wall / 1e6, "bvh_build_s": build_s,
-                          "box_tests_per_ray": sb["bvh_node_tests"] / steps / max(1, rays),
-                          "leaf_tests_per_ray": sb["bvh_leaf_tests"] / steps / max(1, rays),
-                          "exact_retests_per_ray": sb["exact_tests"] / steps / max(1, rays),
-                          "flagged_rays": sb["flagged_rays"]}
-        r.close()
+            r.reset_stats()
+            tp = time.perf_counter()
+            r.render_frame()
+            st = r.stats()
+            wall = time.perf_counter() - tp
+            n_tri, n_sph = st["n_triangles"], st["n_spheres"]
+            tri_share = n_tri / (n_tri + n_sph)
+            ms = st["closest_ms"] + st["anyhit_ms"]
+            tests = (st["closest_tests"] + st["anyhit_tests"]) * tri_share
+            rays = st["rays_primary"] + st["rays_reflect"] + st["rays_shadow"]
+            out["plain_scan"] = {"frame": "512x288", "gpus": 1, "triangles": n_tri, "spheres": n_sph, "filter_form": st["filter_form"],
+                                 "rays": rays, "ray_triangle_tests": tests, "filter_kernels_ms": ms, "frame_ms": wall * 1e3,
+                                 "achieved_tflops": tests * FLOP_TRI / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                                 "frac_of_peak": tests * FLOP_TRI / (ms * 1e-3) / PEAK_FP32_VALU if ms > 0 else 0.0,
+                                 "reference_precision_kernels_ms": st["exact_ms"],
+                                 "note": "42 FLOP per ray x triangle test; reference_precision_kernels_ms holds the listed pairs "
+                                         "and the spheres (FP32 pre-test, survivors in the reference's arithmetic)"}
+            # the same small frame with the default bounding tests
+            r.set_option(abi.RT_OPT_BOUNDING_TESTS, 1)
+            r.set_option(abi.RT_OPT_PROFILE, 0)
+            r.render_frame()
+            r.reset_stats()
+            tp = time.perf_counter()
+            r.render_frame()
+            r.stats()
+            out["bounded_scan"] = {"frame": "512x288", "gpus": 1, "frame_ms": (time.perf_counter() - tp) * 1e3}
+            r.close()
+        job.barrier()
+        cw, ch = (int(v) for v in args.config_size.split("x"))
+        sc8 = Scene.load(path, cw, ch, 8)
+        out["lbvh_8k"] = run_frames(job, args, sc8, steps, in_flight, options=[(abi.RT_OPT_USE_BVH, 1)])
+        out["lbvh_8k"]["bvh_build_s"] = out["lbvh_8k"].pop("options_s")
+    finally:
+        job.barrier()
+        if job.rank == 0:
+            shutil.rmtree(tmp, ignore_errors=True)
     return out
 
 
@@ -224,24 +373,14 @@ def measured_traffic(mode, bounding_test):
 
 def main():
     args = parse()
+    start_ranks_if_asked(args)              # (--gpus N without a launcher: this process only waits for its ranks)
     import torch
     import torch.distributed as dist
     from raytracer_amd import Scene, abi
-    from raytracer_amd.render import FramePipeline, Renderer, TileGather
+    from raytracer_amd.render import FramePipeline, Renderer, make_exchange
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        local_rank %= max(1, torch.cuda.device_count())      # (more ranks than devices: a rehearsal on a smaller box)
-        torch.cuda.set_device(local_rank)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo")
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", torch.cuda.current_device())
+    job = Job(args, torch, dist)
+    world, rank, dev, coll_dev = job.world, job.rank, job.dev, job.coll_dev
 
     scene = Scene.load(args.scene, args.width, args.height, args.depth)
     r = Renderer(scene)
@@ -250,19 +389,15 @@ def main():
     in_flight = max(1, min(4, args.frames_in_flight))
     # one frame buffer per render call in flight: frame i is exchanged while frame i+1 is traced
     frames = [torch.zeros((args.height, args.width, 4), dtype=torch.uint8, device=dev) for _ in range(in_flight)]
-    stream = torch.cuda.current_stream().cuda_stream
-    exchange = TileGather(args.height, args.width, args.tile_rows, rank, world, dev, dist=dist, torch=torch,
-                          host_staging=args.backend != "nccl")
-    coll_dev = dev if args.backend == "nccl" else torch.device("cpu")      # where the small reductions live
+    stream = job.stream
+    exchange = make_exchange(args.exchange, args.height, args.width, args.tile_rows, rank, world, dev, dist=dist, torch=torch,
+                             host_staging=job.host_staging)
     pipe = FramePipeline(r, frames, exchange, rank, world, args.tile_rows, stream)
     step, drain, set_in_flight = pipe.step, pipe.drain, pipe.set_in_flight
 
     def fence():
         drain()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+        job.barrier()
 
     if args.no_overlap:
         r.set_option(abi.RT_OPT_OVERLAP, 0)
@@ -386,6 +521,15 @@ def main():
         rays_total, n_primary, n_reflect, n_shadow = (rays_local, st_timed["rays_primary"], st_timed["rays_reflect"],
                                                       st_timed["rays_shadow"])
 
+    # The headline's renderer gives its workspaces back before the 8K legs take theirs.
+    n_cu, clock_khz = r.device_info()
+    r.close()
+    del frames, pipe
+    torch.cuda.empty_cache()
+    leg_steps = max(1, min(3, args.steps))
+    config4 = config4_leg(job, args, leg_steps, in_flight) if not args.no_config4 and not args.exact_only else None
+    config5 = config5_leg(job, args, leg_steps, in_flight) if not args.no_config5 and not args.exact_only else None
+
     if rank == 0:
         n_tri, n_sph = st["n_triangles"], st["n_spheres"]
         flop_per_test = (FLOP_TRI * n_tri + FLOP_SPH * n_sph) / max(1, n_tri + n_sph)
@@ -453,7 +597,6 @@ def main():
                 "note": "counts from one frame in the counting instances of the scan kernels (RT_OPT_WORK_COUNTERS), "
                         "durations from the serialised leg (HIP events); whole-wave counts: a test a wave executes "
                         "for one asking lane occupies all 64"}
-        n_cu, clock_khz = r.device_info()
         device_peak = (n_cu * 128 * 2 * clock_khz * 1e3) if clock_khz else None
         line = {
             "metric": "Mrays/s (primary+shadow+reflect) teapot 4K depth-5",
@@ -529,9 +672,14 @@ def main():
         line["roofline"] = roof
         if lbvh is not None:
             line["lbvh"] = lbvh
-        if world == 1 and not args.no_config5 and not args.exact_only:
-            line["config5"] = config5_leg(max(1, min(3, args.steps)))
-        if world == 1 and not args.no_cpu_baseline:
+        if config4 is not None:
+            line["config4"] = config4
+        if config5 is not None:
+            line["config5"] = config5
+        line["config"]["exchange"] = ("one transfer per tile, straight into rank 0's frame rows" if args.exchange == "tiles"
+                                      else "one packed transfer per peer") if world > 1 else "none (one rank)"
+        # (rank 0 times the CPU reference while the other ranks wait at the barrier below)
+        if not args.no_cpu_baseline:
             def gpu_rays(w, h):
                 sc = Scene.load(args.scene, w, h, args.depth)
                 rr = Renderer(sc)
@@ -541,7 +689,6 @@ def main():
                 return s2["rays_primary"] + s2["rays_reflect"] + s2["rays_shadow"]
             line["cpu_baseline"] = cpu_baseline(args, gpu_rays)
         print(json.dumps(line), flush=True)
-    r.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

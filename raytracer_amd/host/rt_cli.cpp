@@ -1,7 +1,7 @@
 // Host driver: stands where the reference's main() does (raytracer.cpp:843-868).
 //
 //   rt_render <scene> [out.png] [-w W] [-h H] [-depth D] [-eps E] [-tile ROWS] [-gpus N] [-frames F] [-inflight K]
-//             [-bvh] [-exact] [-stats]
+//             [-packed] [-bvh] [-exact] [-stats]
 //
 // With no options it does what `./raytracer <scene> [out.png]` does: 1000 x 1000, eps 0.05,
 // depth 6, output.png (raytracer.cpp:847-862).  Parsing goes through the host loader
@@ -16,6 +16,16 @@
 // one communicator per GPU from ncclCommInitAll.  The reference has no counterpart: it is one
 // thread on one CPU.
 //
+// -packed (with -gpus N): one message per peer instead of one per tile.  The tiles a GPU owns lie at a constant
+// stride in its frame (tile k, k + N, ...: rth_tile_span), so one strided copy (hipMemcpy2DAsync) packs them into a
+// contiguous buffer, one ncclSend moves it, GPU 0 receives every peer's buffer with one ncclRecv each and one strided
+// copy per peer puts the tiles in place.  Same bytes in GPU 0's frame as the per-tile exchange.
+//
+// A GPU that fails (upload, allocation, a render call) must not leave the others waiting in an exchange it will
+// never join: the ranks agree after set-up (a host barrier and a shared flag) and none enters the frame loop unless
+// all are ready; a failure inside the loop aborts every communicator (ncclCommAbort), which ends transfers already
+// enqueued.  The process then reports the failing GPU's message and exits with status 1.
+//
 // -frames F -inflight K (with -gpus; -gpus 1 if that is not given): the frame is rendered F times with up to K
 // render calls in flight per GPU (RT_OPT_FRAMES_IN_FLIGHT), each into a frame buffer of its own; the exchange
 // of frame i is enqueued behind rt_join(stream, K - 1), beside the tracing of the frames after it.  The last
@@ -28,6 +38,8 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -44,19 +56,101 @@ struct RankResult {
     double render_s = 0;          // enqueue of the tiles until this rank's part of the exchange has finished
 };
 
+// What the rank threads of one process share to agree on success before they meet in a collective.
+struct RankSync {
+    explicit RankSync(int n) : n_ranks(n) {}
+    const int n_ranks;
+    std::atomic<int> failed{0};
+    std::vector<ncclComm_t>* comms = nullptr;
+    std::atomic<int> aborted{0};
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0, generation = 0;
+    // every rank calls it once per meeting point; returns when all have
+    void meet() {
+        std::unique_lock<std::mutex> lock(m);
+        const int gen = generation;
+        if (++arrived == n_ranks) { arrived = 0; generation++; cv.notify_all(); return; }
+        cv.wait(lock, [&] { return generation != gen; });
+    }
+    // a rank failed while others may already wait in an exchange: end every communicator's transfers (once)
+    void abort_all() {
+        failed.store(1);
+        if (aborted.exchange(1) || !comms) return;
+        for (ncclComm_t c : *comms) (void)ncclCommAbort(c);
+    }
+};
+
+// Test hook: RT_RENDER_FAIL="<rank>:<where>" makes that rank fail on purpose, where = "setup" (before the ranks
+// have agreed to start) or "frame" (inside the frame loop, after its first render call).
+bool forced_failure(int rank, const char* where) {
+    const char* env = std::getenv("RT_RENDER_FAIL");
+    if (!env) return false;
+    return std::string(env) == std::to_string(rank) + ":" + where;
+}
+
 // One GPU's share of an N-GPU frame.  Rank 0 ends up with the whole frame in `image`.
 void run_rank(int rank, int n_ranks, ncclComm_t comm, const rt_scene_desc* desc, int tile_rows, bool bvh, bool exact,
-              int n_frames, int in_flight, std::vector<uint8_t>* image, RankResult* out) {
+              int n_frames, int in_flight, bool packed, RankSync* sync, std::vector<uint8_t>* image, RankResult* out) {
     auto fail = [&](const std::string& what) { out->rc = 1; out->error = "GPU " + std::to_string(rank) + ": " + what; };
-    if (hipSetDevice(rank) != hipSuccess) return fail("hipSetDevice failed");
     const int W = desc->width, H = desc->height;
     const size_t frame_bytes = (size_t)W * H * 4;
     rt_ctx* ctx = nullptr;
     std::vector<void*> frames((size_t)in_flight, nullptr);      // one buffer per render call in flight
     hipStream_t stream = nullptr;
-    // one frame's exchange, enqueued on `stream`: every tile's rows from its owner straight into GPU 0's frame
+    const int n_tiles = (H + tile_rows - 1) / tile_rows;
+    // ---- the packed exchange: per rank, its full tiles (tile_rows rows each) at a constant stride, and at most one
+    // clipped tile (the frame's last, when the height is not a multiple of tile_rows) ----
+    struct Share { int full = 0; size_t first_off = 0; bool clipped = false; size_t clip_off = 0, clip_bytes = 0; size_t bytes = 0; };
+    const size_t tile_bytes = (size_t)tile_rows * W * 4;
+    auto share_of = [&](int r) {
+        Share s;
+        for (int k = r; k < n_tiles; k += n_ranks) {
+            size_t off = 0, bytes = 0;
+            if (rth_tile_span(W, H, tile_rows, n_ranks, k, &off, &bytes) != r) continue;
+            if (bytes == tile_bytes) { s.full++; s.first_off = off; }       // (offsets fall as k rises: the last full tile lies lowest)
+            else { s.clipped = true; s.clip_off = off; s.clip_bytes = bytes; }
+        }
+        s.bytes = (size_t)s.full * tile_bytes + s.clip_bytes;
+        return s;
+    };
+    std::vector<Share> shares;
+    std::vector<size_t> share_at;                 // GPU 0: where each peer's buffer starts in `staging`
+    void* staging = nullptr;                      // GPU 0: all peers' buffers; other GPUs: their own
+    // tiles <-> buffer: one strided copy for the full tiles (stride n_ranks tiles in the frame), one for the clipped tile
+    auto strided = [&](void* frame, void* buf, const Share& s, bool to_buffer) -> hipError_t {
+        hipError_t e = hipSuccess;
+        char* f = (char*)frame + s.first_off;
+        if (s.full > 0)
+            e = to_buffer ? hipMemcpy2DAsync(buf, tile_bytes, f, (size_t)n_ranks * tile_bytes, tile_bytes, (size_t)s.full, hipMemcpyDeviceToDevice, stream)
+                          : hipMemcpy2DAsync(f, (size_t)n_ranks * tile_bytes, buf, tile_bytes, tile_bytes, (size_t)s.full, hipMemcpyDeviceToDevice, stream);
+        if (e == hipSuccess && s.clipped) {
+            char* b = (char*)buf + (size_t)s.full * tile_bytes;
+            e = to_buffer ? hipMemcpyAsync(b, (char*)frame + s.clip_off, s.clip_bytes, hipMemcpyDeviceToDevice, stream)
+                          : hipMemcpyAsync((char*)frame + s.clip_off, b, s.clip_bytes, hipMemcpyDeviceToDevice, stream);
+        }
+        return e;
+    };
+    // one frame's exchange, enqueued on `stream`
     auto exchange = [&](void* frame) -> ncclResult_t {
-        const int n_tiles = (H + tile_rows - 1) / tile_rows;
+        if (n_ranks == 1) return ncclSuccess;
+        if (packed) {
+            if (rank != 0 && shares[(size_t)rank].bytes && strided(frame, staging, shares[(size_t)rank], true) != hipSuccess) return ncclUnhandledCudaError;
+            ncclResult_t nr = ncclGroupStart();
+            if (rank == 0) {
+                for (int p = 1; p < n_ranks && nr == ncclSuccess; p++)
+                    if (shares[(size_t)p].bytes) nr = ncclRecv((char*)staging + share_at[(size_t)p], shares[(size_t)p].bytes, ncclUint8, p, comm, stream);
+            } else if (shares[(size_t)rank].bytes) {
+                nr = ncclSend(staging, shares[(size_t)rank].bytes, ncclUint8, 0, comm, stream);
+            }
+            const ncclResult_t ne = ncclGroupEnd();
+            if (nr == ncclSuccess) nr = ne;
+            if (rank == 0)
+                for (int p = 1; p < n_ranks && nr == ncclSuccess; p++)
+                    if (shares[(size_t)p].bytes && strided(frame, (char*)staging + share_at[(size_t)p], shares[(size_t)p], false) != hipSuccess) nr = ncclUnhandledCudaError;
+            return nr;
+        }
+        // every tile's rows from its owner straight into GPU 0's frame
         ncclResult_t nr = ncclGroupStart();
         for (int k = 0; k < n_tiles && nr == ncclSuccess; k++) {
             size_t off = 0, bytes = 0;
@@ -69,7 +163,11 @@ void run_rank(int rank, int n_ranks, ncclComm_t comm, const rt_scene_desc* desc,
         const ncclResult_t ne = ncclGroupEnd();
         return nr == ncclSuccess ? ne : nr;
     };
+    bool met = false;                             // this rank has been to the meeting point after set-up
     do {
+        // ---- set-up: everything that can fail before the first collective ----
+        if (hipSetDevice(rank) != hipSuccess) { fail("hipSetDevice failed"); break; }
+        if (forced_failure(rank, "setup")) { fail("failure forced by RT_RENDER_FAIL (setup)"); break; }
         if (rt_upload_scene(&ctx, desc)) { fail(rt_last_error()); break; }
         if (exact && rt_set_option(ctx, RT_OPT_EXACT_ONLY, 1)) { fail(rt_last_error()); break; }
         if (bvh && rt_set_option(ctx, RT_OPT_USE_BVH, 1)) { fail(rt_last_error()); break; }
@@ -79,14 +177,30 @@ void run_rank(int rank, int n_ranks, ncclComm_t comm, const rt_scene_desc* desc,
             ok = ok && hipMalloc(&f, frame_bytes) == hipSuccess && hipMemset(f, 0, frame_bytes) == hipSuccess;
         if (!ok) { fail("cannot allocate the frame"); break; }
         if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { fail("cannot create a stream"); break; }
+        if (packed && n_ranks > 1) {
+            size_t total = 0;
+            for (int r = 0; r < n_ranks; r++) {
+                shares.push_back(share_of(r));
+                share_at.push_back(total);
+                if (r > 0) total += shares.back().bytes;
+            }
+            const size_t want = rank == 0 ? total : shares[(size_t)rank].bytes;
+            if (want && hipMalloc(&staging, want) != hipSuccess) { fail("cannot allocate the exchange buffer"); break; }
+        }
+        // ---- agree: nobody starts unless everybody can ----
+        if (out->rc) sync->failed.store(1);
+        sync->meet();
+        met = true;
+        if (sync->failed.load()) break;                       // (the failing rank reports; the others just leave)
         const auto t0 = std::chrono::steady_clock::now();
         std::vector<void*> waiting;                   // frames traced (or being traced) and not yet exchanged
         ncclResult_t nr = ncclSuccess;
         int rc = 0;
-        for (int i = 0; i < n_frames && !rc && nr == ncclSuccess; i++) {
+        for (int i = 0; i < n_frames && !rc && nr == ncclSuccess && !sync->failed.load(); i++) {
             void* frame = frames[(size_t)(i % in_flight)];
             rc = rt_bind_frame(ctx, frame, frame_bytes);
             if (!rc) rc = rt_render_tiles(ctx, rank, tile_rows, n_ranks, stream);
+            if (!rc && i == 0 && forced_failure(rank, "frame")) { fail("failure forced by RT_RENDER_FAIL (frame)"); rc = -1; }
             if (rc) break;
             waiting.push_back(frame);
             if ((int)waiting.size() == in_flight) {
@@ -97,11 +211,17 @@ void run_rank(int rank, int n_ranks, ncclComm_t comm, const rt_scene_desc* desc,
                 waiting.erase(waiting.begin());
             }
         }
-        if (!rc) rc = rt_join(ctx, stream, 0);
-        for (size_t k = 0; k < waiting.size() && !rc && nr == ncclSuccess; k++) nr = exchange(waiting[k]);
-        if (rc) { fail(rt_last_error()); break; }
-        if (nr != ncclSuccess) { fail(std::string("RCCL exchange: ") + ncclGetErrorString(nr)); break; }
-        if (hipStreamSynchronize(stream) != hipSuccess) { fail("stream synchronisation failed"); break; }
+        if (!rc && !sync->failed.load()) rc = rt_join(ctx, stream, 0);
+        for (size_t k = 0; k < waiting.size() && !rc && nr == ncclSuccess && !sync->failed.load(); k++) nr = exchange(waiting[k]);
+        if (rc || nr != ncclSuccess) {
+            if (!out->rc) fail(rc ? std::string(rt_last_error()) : std::string("RCCL exchange: ") + ncclGetErrorString(nr));
+            sync->abort_all();                                // peers may already wait for this rank's tiles
+            break;
+        }
+        if (hipStreamSynchronize(stream) != hipSuccess || sync->failed.load()) {
+            if (!sync->failed.load()) { fail("stream synchronisation failed"); sync->abort_all(); }
+            break;
+        }
         out->render_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (rt_get_stats(ctx, &out->stats)) { fail(rt_last_error()); break; }
         if (rank == 0) {
@@ -110,23 +230,28 @@ void run_rank(int rank, int n_ranks, ncclComm_t comm, const rt_scene_desc* desc,
             if (hipMemcpy(image->data(), last, frame_bytes, hipMemcpyDeviceToHost) != hipSuccess) { fail("cannot copy the frame to the host"); break; }
         }
     } while (false);
+    if (!met) {                                   // (a rank that failed during set-up still keeps the appointment)
+        if (out->rc) sync->failed.store(1);
+        sync->meet();
+    }
     if (ctx) rt_free(ctx);                  // (waits for everything the context has enqueued)
     if (stream) (void)hipStreamDestroy(stream);
     for (void* f : frames) if (f) (void)hipFree(f);
+    if (staging) (void)hipFree(staging);
 }
 
 }  // namespace
 
 int main(int argc, char** argv) {
     if (argc < 2) {
-        fprintf(stderr, "usage: %s <scene> [out.png] [-w W] [-h H] [-depth D] [-eps E] [-tile ROWS] [-gpus N] [-frames F] [-inflight K] [-bvh] [-exact] [-stats]\n",
+        fprintf(stderr, "usage: %s <scene> [out.png] [-w W] [-h H] [-depth D] [-eps E] [-tile ROWS] [-gpus N] [-frames F] [-inflight K] [-packed] [-bvh] [-exact] [-stats]\n",
                 argv[0]);
         return 2;
     }
     std::string scene = argv[1], out = "output.png";
     int width = 1000, height = 1000, depth = -1, tile = 0, gpus = 0, n_frames = 1, in_flight = 1;
     float eps = 0.f;
-    bool bvh = false, exact = false, stats = false;
+    bool bvh = false, exact = false, stats = false, packed = false;
     int pos = 0;
     for (int i = 2; i < argc; i++) {
         std::string a = argv[i];
@@ -142,6 +267,7 @@ int main(int argc, char** argv) {
         else if (a == "-gpus") gpus = atoi(need("-gpus"));
         else if (a == "-frames") n_frames = atoi(need("-frames"));
         else if (a == "-inflight") in_flight = atoi(need("-inflight"));
+        else if (a == "-packed") packed = true;
         else if (a == "-bvh") bvh = true;
         else if (a == "-exact") exact = true;
         else if (a == "-stats") stats = true;
@@ -189,15 +315,18 @@ int main(int argc, char** argv) {
         printf("Rendering Scene...\n");
         const int rows = tile > 0 ? tile : 16;
         std::vector<RankResult> results(gpus);
+        RankSync sync(gpus);
+        sync.comms = &comms;
         auto t0 = now();
         {
             std::vector<std::thread> pool;
             for (int g = 0; g < gpus; g++)
-                pool.emplace_back(run_rank, g, gpus, comms[g], rth_desc(sc), rows, bvh, exact, n_frames, in_flight, &image, &results[g]);
+                pool.emplace_back(run_rank, g, gpus, comms[g], rth_desc(sc), rows, bvh, exact, n_frames, in_flight, packed, &sync, &image, &results[g]);
             for (auto& th : pool) th.join();
         }
         const double wall = since(t0);         // upload, render, exchange and the copy to the host, all ranks
-        for (int g = 0; g < gpus; g++) (void)ncclCommDestroy(comms[g]);
+        if (!sync.aborted.load())              // (an aborted communicator is gone already)
+            for (int g = 0; g < gpus; g++) (void)ncclCommDestroy(comms[g]);
         for (int g = 0; g < gpus; g++) {
             if (results[g].rc) { fprintf(stderr, "%s\n", results[g].error.c_str()); status = 1; }
             secs = std::max(secs, results[g].render_s);

@@ -126,36 +126,49 @@ def test_config5_million_triangles_8k_through_the_lbvh(oracle, tmp_path):
 
 def test_two_rank_benchmark_flow_on_one_gpu():
     """The N-rank driver end to end with two ranks sharing this box's GPU (gloo instead of
-    RCCL, which refuses two ranks on one device): interleaved tiles per rank, gather to rank 0,
-    max-over-ranks timing, summed ray counts.  The ray total must be the single-process one."""
+    RCCL, which refuses two ranks on one device), started the way the round's driver starts it:
+    `python bench.py --gpus 2`, which launches its two ranks itself.  Interleaved tiles per rank,
+    gather to rank 0 (both forms of the exchange), max-over-ranks timing, summed ray counts; the
+    config4 / config5 legs run under two ranks as well (at a reduced frame size).  The ray total
+    and rank 0's frame must be the single-process ones."""
     import json
-    import socket
     import subprocess
     import sys
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     import tempfile
-    common = ["--steps", "4", "--warmup", "0", "--width", "640", "--height", "360", "--no-cpu-baseline", "--no-lbvh", "--no-config5"]
+    bench = [sys.executable, os.path.join(ROOT, "bench.py")]
+    common = ["--steps", "4", "--warmup", "0", "--width", "640", "--height", "360", "--no-cpu-baseline", "--no-lbvh"]
+    no_legs = ["--no-config4", "--no-config5"]
+
+    def last_line(out):
+        return json.loads([ln for ln in out.strip().splitlines() if ln.startswith("{")][-1])
+
     with tempfile.TemporaryDirectory() as tmp:
-        f1, f2, f3 = (os.path.join(tmp, n) for n in ("one.npy", "two.npy", "two_serial.npy"))
-        one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dump-frame", f1] + common,
+        f1, f2, f3, f4 = (os.path.join(tmp, n) for n in ("one.npy", "two.npy", "two_serial.npy", "two_packed.npy"))
+        one = subprocess.run(bench + ["--gpus", "1", "--dump-frame", f1] + common + no_legs,
                              check=True, capture_output=True, text=True, timeout=300).stdout
-        launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-                  "--gpus", "2", "--backend", "gloo"]
-        # four frames in flight per rank (the default): a frame is exchanged three steps after its render call
-        two = subprocess.run(launch + ["--dump-frame", f2] + common, check=True, capture_output=True, text=True, timeout=300).stdout
-        # ... and one frame at a time
-        subprocess.run(launch + ["--dump-frame", f3, "--frames-in-flight", "1"] + common, check=True, capture_output=True,
+        two_ranks = bench + ["--gpus", "2", "--backend", "gloo"]
+        # four frames in flight per rank (the default): a frame is exchanged three steps after its render call;
+        # with the config4 / config5 legs at a small frame size
+        two = subprocess.run(two_ranks + ["--dump-frame", f2, "--config-size", "640x360"] + common, check=True, capture_output=True,
+                             text=True, timeout=600).stdout
+        # ... one frame at a time
+        subprocess.run(two_ranks + ["--dump-frame", f3, "--frames-in-flight", "1"] + common + no_legs, check=True, capture_output=True,
                        text=True, timeout=300)
-        a = json.loads(one.strip().splitlines()[-1])
-        b = json.loads([ln for ln in two.strip().splitlines() if ln.startswith("{")][-1])
-        assert a["n_gpus"] == 1 and b["n_gpus"] == 2 and b["value"] > 0
-        assert a["config"]["rays_per_frame"] == b["config"]["rays_per_frame"]
+        # ... and one packed transfer per peer instead of one per tile
+        packed = subprocess.run(two_ranks + ["--dump-frame", f4, "--exchange", "packed"] + common + no_legs, check=True,
+                                capture_output=True, text=True, timeout=300).stdout
+        a, b, c = last_line(one), last_line(two), last_line(packed)
+        assert a["n_gpus"] == 1 and b["n_gpus"] == 2 and b["value"] > 0 and c["n_gpus"] == 2
+        assert a["config"]["rays_per_frame"] == b["config"]["rays_per_frame"] == c["config"]["rays_per_frame"]
         assert a["config"]["frames_in_flight"] == 4 and b["config"]["frames_in_flight"] == 4
+        for leg in (b["config4"]["brute_force"], b["config4"]["lbvh"], b["config5"]["lbvh_8k"]):
+            assert leg["frame"] == "640x360" and leg["Mrays_per_s"] > 0 and leg["rays_per_frame"] >= 640 * 360
+        assert b["config4"]["n_gpus"] == 2 and b["config5"]["n_gpus"] == 2
+        assert b["config4"]["brute_force"]["rays_per_frame"] == b["config4"]["lbvh"]["rays_per_frame"]
+        assert b["config5"]["lbvh_8k"]["triangles"] == 1000000 and b["config5"]["plain_scan"]["frac_of_peak"] > 0
         # rank 0's frame after the exchange is the single-process frame, byte for byte
         want = np.load(f1)
         assert want.any()
         assert np.array_equal(np.load(f2), want)
         assert np.array_equal(np.load(f3), want)
+        assert np.array_equal(np.load(f4), want)

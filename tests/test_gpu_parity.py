@@ -458,3 +458,36 @@ def test_cli_driver_frames_in_flight(tmp_path):
         assert np.array_equal(oracle_api.load_png(str(out)), oracle_api.load_png(str(one))), (frames, in_flight)
     res = subprocess.run([exe, scene, str(one), "-inflight", "5"] + common, capture_output=True, text=True)
     assert res.returncode == 2
+
+
+def test_cli_driver_a_failing_rank_ends_the_run(tmp_path):
+    """`rt_render -gpus N`: a GPU that fails -- during set-up, or inside the frame loop -- must end the run with the
+    failing GPU's message and status 1 in bounded time (the ranks agree after set-up; a failure inside the loop
+    aborts the communicators), never leave the process waiting in an exchange.  RT_RENDER_FAIL forces the failure."""
+    import subprocess
+    exe = os.path.join(ROOT, "raytracer_amd", "rt_render")
+    scene = os.path.join(ROOT, "scenes", "mixed_xf.scene")
+    out = tmp_path / "never.png"
+    for where in ("setup", "frame"):
+        env = dict(os.environ, RT_RENDER_FAIL=f"0:{where}")
+        res = subprocess.run([exe, scene, str(out), "-gpus", "1", "-w", "160", "-h", "120", "-depth", "3", "-frames", "3", "-inflight", "2"],
+                             capture_output=True, text=True, env=env, timeout=120)
+        assert res.returncode == 1, (where, res.returncode, res.stderr)
+        assert "GPU 0: failure forced by RT_RENDER_FAIL" in res.stderr and not out.exists()
+    # (a failure forced on a rank that does not exist changes nothing)
+    res = subprocess.run([exe, scene, str(out), "-gpus", "1", "-w", "160", "-h", "120", "-depth", "3"], capture_output=True, text=True,
+                         env=dict(os.environ, RT_RENDER_FAIL="5:setup"), timeout=120)
+    assert res.returncode == 0 and out.exists()
+
+
+def test_cli_driver_packed_exchange_option(tmp_path):
+    """`rt_render -gpus 1 -packed`: the option is accepted and the one-rank frame is the plain one (with one rank
+    neither form of the exchange moves anything; the span arithmetic of both is checked on CPU)."""
+    import subprocess
+    exe = os.path.join(ROOT, "raytracer_amd", "rt_render")
+    scene = os.path.join(ROOT, "scenes", "mixed_xf.scene")
+    a, b = tmp_path / "a.png", tmp_path / "b.png"
+    common = ["-w", "160", "-h", "117", "-depth", "4", "-tile", "8"]
+    assert subprocess.run([exe, scene, str(a), "-gpus", "1"] + common, capture_output=True, text=True).returncode == 0
+    assert subprocess.run([exe, scene, str(b), "-gpus", "1", "-packed"] + common, capture_output=True, text=True).returncode == 0
+    assert np.array_equal(oracle_api.load_png(str(a)), oracle_api.load_png(str(b)))

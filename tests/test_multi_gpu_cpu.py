@@ -37,7 +37,7 @@ def _pattern(H, W):
     return ((y * 7 + x * 3 + c * 11) % 251).to(torch.uint8)
 
 
-def _worker(rank, world, port, H, W, tile_rows, out_path):
+def _worker(rank, world, port, H, W, tile_rows, out_path, kind="tiles"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -46,19 +46,28 @@ def _worker(rank, world, port, H, W, tile_rows, out_path):
     for y0, y1 in tiles_of_rank(H, tile_rows, rank, world):      # film rows; frame row = H-1-y
         for y in range(y0, y1):
             frame[H - 1 - y] = want[H - 1 - y]
-    gather_frame(None, frame, tile_rows, rank, world, dist=dist, torch=torch)
+    gather_frame(None, frame, tile_rows, rank, world, dist=dist, torch=torch, kind=kind)
     if rank == 0:
         np.save(out_path, frame.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("kind", ["tiles", "packed"])
 @pytest.mark.parametrize("H,W,tile_rows,world", [(70, 33, 8, 2), (64, 16, 16, 2), (37, 9, 5, 3), (50, 7, 16, 4)])
-def test_gather_rebuilds_the_frame(tmp_path, H, W, tile_rows, world):
+def test_gather_rebuilds_the_frame(tmp_path, H, W, tile_rows, world, kind):
+    """Both exchanges (one transfer per tile / one packed transfer per peer) leave the whole frame on rank 0."""
     out = str(tmp_path / "frame.npy")
-    mp.spawn(_worker, args=(world, _free_port(), H, W, tile_rows, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), H, W, tile_rows, out, kind), nprocs=world, join=True)
     got = np.load(out)
     assert np.array_equal(got, _pattern(H, W).numpy())
+
+
+def test_packed_exchange_with_a_rank_that_owns_nothing(tmp_path):
+    """Fewer tiles than ranks: the ranks without a tile send nothing and rank 0 expects nothing from them."""
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(4, _free_port(), 20, 5, 16, out, "packed"), nprocs=4, join=True)
+    assert np.array_equal(np.load(out), _pattern(20, 5).numpy())
 
 
 def test_tile_ownership_is_a_partition():
@@ -125,14 +134,14 @@ class _StandInRenderer:
         self.log.append(("join", keep_latest))
 
 
-def _pipeline_worker(rank, world, port, H, W, tile_rows, in_flight, n_frames, out_path):
-    from raytracer_amd.render import FramePipeline, TileGather
+def _pipeline_worker(rank, world, port, H, W, tile_rows, in_flight, n_frames, out_path, kind="tiles"):
+    from raytracer_amd.render import FramePipeline, make_exchange
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     r = _StandInRenderer(H, W, tile_rows)
     frames = [torch.zeros((H, W, 4), dtype=torch.uint8) for _ in range(in_flight)]
-    gather = TileGather(H, W, tile_rows, rank, world, "cpu", dist=dist, torch=torch)
+    gather = make_exchange(kind, H, W, tile_rows, rank, world, "cpu", dist=dist, torch=torch)
     got, order = [], []
 
     def exchange(frame):
@@ -158,14 +167,15 @@ def _pipeline_worker(rank, world, port, H, W, tile_rows, in_flight, n_frames, ou
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("kind", ["tiles", "packed"])
 @pytest.mark.parametrize("H,W,tile_rows,world,in_flight,n_frames", [(70, 9, 8, 2, 3, 7), (37, 5, 5, 3, 2, 4), (64, 4, 16, 2, 4, 2),
                                                                      (50, 7, 16, 2, 1, 3)])
-def test_frames_in_flight_are_each_exchanged_once_in_order(tmp_path, H, W, tile_rows, world, in_flight, n_frames):
+def test_frames_in_flight_are_each_exchanged_once_in_order(tmp_path, H, W, tile_rows, world, in_flight, n_frames, kind):
     """FramePipeline on gloo ranks with a stand-in renderer: with k calls in flight the exchange of frame i is
     issued k - 1 steps after its render call and behind an rt_join that covers it; rank 0 ends up with every
     frame, whole, in order -- also when fewer frames than lanes are rendered."""
     out = str(tmp_path / "frames.npy")
-    mp.spawn(_pipeline_worker, args=(world, _free_port(), H, W, tile_rows, in_flight, n_frames, out), nprocs=world, join=True)
+    mp.spawn(_pipeline_worker, args=(world, _free_port(), H, W, tile_rows, in_flight, n_frames, out, kind), nprocs=world, join=True)
     got = np.load(out)
     assert got.shape[0] == n_frames + 2
     for c in range(n_frames + 2):
