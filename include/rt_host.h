@@ -47,6 +47,17 @@ int rth_write_png(const char* path, const uint8_t* rgba, int width, int height);
  * process and no exchange). */
 int rth_tile_span(int width, int height, int tile_rows, int n_ranks, int k, size_t* offset, size_t* bytes);
 
+/* The packed form of that exchange (one message per peer): what rank `rank` of `n_ranks` owns, as a
+ * strided region of the frame.  Its full tiles (tile_rows rows each) lie at a constant stride of
+ * n_ranks tiles: *n_full of them, the lowest at byte offset *first_offset, each *tile_bytes long,
+ * *stride_bytes apart -- one 2-D copy (hipMemcpy2DAsync: width = tile_bytes, height = n_full,
+ * source pitch = stride_bytes) packs them into a contiguous buffer in ascending frame order.  The
+ * frame's last tile is clipped when the height is not a multiple of tile_rows; if this rank owns it,
+ * *clip_bytes > 0 and it lies at *clip_offset (it follows the full tiles in the packed buffer).
+ * Returns 0, or RT_ERR_ARG. */
+int rth_packed_share(int width, int height, int tile_rows, int n_ranks, int rank, int* n_full, size_t* first_offset,
+                     size_t* tile_bytes, size_t* stride_bytes, size_t* clip_offset, size_t* clip_bytes);
+
 const char* rth_last_error(void);
 
 #ifdef __cplusplus

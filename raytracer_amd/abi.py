@@ -78,7 +78,7 @@ class RtStats(C.Structure):
 
 
 HOST_SYMBOLS = ["rth_load_scene", "rth_load_blob", "rth_save_blob", "rth_desc", "rth_free_scene",
-                "rth_write_png", "rth_tile_span", "rth_last_error"]
+                "rth_write_png", "rth_tile_span", "rth_packed_share", "rth_last_error"]
 DEVICE_SYMBOLS = ["rt_upload_scene", "rt_set_option", "rt_render_tile", "rt_render_tiles", "rt_join", "rt_render_tile_noalloc",
                   "rt_bind_frame", "rt_download", "rt_primary_hits", "rt_bounce_probe", "rt_queue_pixel", "rt_get_stats", "rt_reset_stats", "rt_device_info",
                   "rt_free", "rt_last_error"]
@@ -115,6 +115,8 @@ def host_lib():
         lib.rth_write_png.restype = C.c_int
         lib.rth_tile_span.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         lib.rth_tile_span.restype = C.c_int
+        lib.rth_packed_share.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)] + [C.POINTER(C.c_size_t)] * 5
+        lib.rth_packed_share.restype = C.c_int
         lib.rth_last_error.argtypes = []
         lib.rth_last_error.restype = C.c_char_p
         _host = lib

@@ -102,15 +102,12 @@ void run_rank(int rank, int n_ranks, ncclComm_t comm, const rt_scene_desc* desc,
     // ---- the packed exchange: per rank, its full tiles (tile_rows rows each) at a constant stride, and at most one
     // clipped tile (the frame's last, when the height is not a multiple of tile_rows) ----
     struct Share { int full = 0; size_t first_off = 0; bool clipped = false; size_t clip_off = 0, clip_bytes = 0; size_t bytes = 0; };
-    const size_t tile_bytes = (size_t)tile_rows * W * 4;
+    size_t tile_bytes = (size_t)tile_rows * W * 4;
     auto share_of = [&](int r) {
         Share s;
-        for (int k = r; k < n_tiles; k += n_ranks) {
-            size_t off = 0, bytes = 0;
-            if (rth_tile_span(W, H, tile_rows, n_ranks, k, &off, &bytes) != r) continue;
-            if (bytes == tile_bytes) { s.full++; s.first_off = off; }       // (offsets fall as k rises: the last full tile lies lowest)
-            else { s.clipped = true; s.clip_off = off; s.clip_bytes = bytes; }
-        }
+        size_t tb = 0, stride = 0;
+        if (rth_packed_share(W, H, tile_rows, n_ranks, r, &s.full, &s.first_off, &tb, &stride, &s.clip_off, &s.clip_bytes)) s = Share{};
+        s.clipped = s.clip_bytes > 0;
         s.bytes = (size_t)s.full * tile_bytes + s.clip_bytes;
         return s;
     };

@@ -668,6 +668,23 @@ int rth_tile_span(int width, int height, int tile_rows, int n_ranks, int k, size
     return k % n_ranks;
 }
 
+int rth_packed_share(int width, int height, int tile_rows, int n_ranks, int rank, int* n_full, size_t* first_offset,
+                     size_t* tile_bytes, size_t* stride_bytes, size_t* clip_offset, size_t* clip_bytes) {
+    if (width <= 0 || height <= 0 || tile_rows <= 0 || n_ranks <= 0 || rank < 0 || rank >= n_ranks || !n_full || !first_offset ||
+        !tile_bytes || !stride_bytes || !clip_offset || !clip_bytes)
+        return fail(RT_ERR_ARG, "rth_packed_share: bad argument");
+    const int n_tiles = (height + tile_rows - 1) / tile_rows;
+    const size_t tb = (size_t)tile_rows * (size_t)width * 4;
+    *n_full = 0; *first_offset = 0; *tile_bytes = tb; *stride_bytes = (size_t)n_ranks * tb; *clip_offset = 0; *clip_bytes = 0;
+    for (int k = rank; k < n_tiles; k += n_ranks) {
+        size_t off = 0, bytes = 0;
+        if (rth_tile_span(width, height, tile_rows, n_ranks, k, &off, &bytes) != rank) return fail(RT_ERR_ARG, "rth_packed_share: span");
+        if (bytes == tb) { (*n_full)++; *first_offset = off; }      // (offsets fall as k rises: the last full tile lies lowest)
+        else { *clip_offset = off; *clip_bytes = bytes; }
+    }
+    return 0;
+}
+
 const rt_scene_desc* rth_desc(const rth_scene* s) { return s ? &s->d : nullptr; }
 void rth_free_scene(rth_scene* s) { delete s; }
 const char* rth_last_error(void) { return g_err.c_str(); }

@@ -205,3 +205,47 @@ def test_one_rank_without_a_consumer_joins_only_at_the_end():
             assert joins_before_drain == [("join", 3)] * 6 and joins[-1] == ("join", 0) and seen == list(range(9))
         else:
             assert joins_before_drain == [] and joins == [("join", 0)]
+
+
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
+@pytest.mark.parametrize("H,W,T", [(2160, 3840, 16), (1000, 10, 16), (37, 9, 5), (50, 7, 16), (16, 4, 16), (1, 1, 16)])
+def test_packed_share_describes_a_ranks_tiles_as_one_strided_region(world, H, W, T):
+    """rth_packed_share (what `rt_render -packed` feeds hipMemcpy2DAsync with): packing every rank's share with
+    exactly that strided copy and unpacking it on the other side rebuilds the frame; a rank's packed buffer holds
+    exactly its tiles' bytes."""
+    import ctypes as C
+    from raytracer_amd import abi
+    lib = abi.host_lib()
+    frame = np.random.default_rng(5).integers(0, 256, size=H * W * 4, dtype=np.uint8)
+    rebuilt = np.zeros_like(frame)
+    covered = 0
+    for rank in range(world):
+        n_full = C.c_int()
+        first, tb, stride, clip_off, clip_bytes = (C.c_size_t() for _ in range(5))
+        assert lib.rth_packed_share(W, H, T, world, rank, C.byref(n_full), C.byref(first), C.byref(tb), C.byref(stride),
+                                    C.byref(clip_off), C.byref(clip_bytes)) == 0
+        assert tb.value == T * W * 4 and stride.value == world * T * W * 4
+        # the 2-D copy: n_full rows of tile_bytes, source pitch = stride
+        packed = [frame[first.value + i * stride.value: first.value + i * stride.value + tb.value] for i in range(n_full.value)]
+        if clip_bytes.value:
+            packed.append(frame[clip_off.value: clip_off.value + clip_bytes.value])
+        buf = np.concatenate(packed) if packed else np.zeros(0, dtype=np.uint8)
+        own = sum((b - a) * W * 4 for o, a, b in tile_spans(W, H, T, world) if o == rank)
+        assert buf.size == own
+        covered += buf.size
+        # ... and back
+        for i in range(n_full.value):
+            rebuilt[first.value + i * stride.value: first.value + i * stride.value + tb.value] = buf[i * tb.value:(i + 1) * tb.value]
+        if clip_bytes.value:
+            rebuilt[clip_off.value: clip_off.value + clip_bytes.value] = buf[n_full.value * tb.value:]
+        # the strided region is exactly this rank's spans
+        mine = np.zeros(H * W * 4, dtype=bool)
+        for o, a, b in tile_spans(W, H, T, world):
+            if o == rank:
+                mine[a * W * 4: b * W * 4] = True
+        got = np.zeros_like(mine)
+        for i in range(n_full.value):
+            got[first.value + i * stride.value: first.value + i * stride.value + tb.value] = True
+        got[clip_off.value: clip_off.value + clip_bytes.value] = True
+        assert np.array_equal(got, mine)
+    assert covered == frame.size and np.array_equal(rebuilt, frame)
