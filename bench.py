@@ -221,7 +221,8 @@ def run_frames(job, args, scene, steps, in_flight, options=()):
            "triangles": st["n_triangles"], "spheres": st["n_spheres"], "lights": scene.desc.n_lights,
            "flagged_rays": st["flagged_rays"], "filter_form": st["filter_form"]}
     if st["bvh_node_tests"]:
-        out.update({"box_tests_per_ray": st["bvh_node_tests"] / max(1, rays), "leaf_tests_per_ray": st["bvh_leaf_tests"] / max(1, rays),
+        out.update({"in_plane_origin_scan": "on" if st["bvh_plane_guard"] else "off (the calibration frame found no ray that needs it)",
+                    "box_tests_per_ray": st["bvh_node_tests"] / max(1, rays), "leaf_tests_per_ray": st["bvh_leaf_tests"] / max(1, rays),
                     "exact_retests_per_ray": st["exact_tests"] / max(1, rays)})
     r.close()
     del frames
@@ -506,7 +507,10 @@ def main():
                 "box_tests_per_ray": sb["bvh_node_tests"] / max(1, lb_rays),
                 "leaf_tests_per_ray": sb["bvh_leaf_tests"] / max(1, lb_rays),
                 "exact_retests_per_ray": sb["exact_tests"] / max(1, lb_rays),
-                "note": "frames byte-identical to brute force on the bundled scenes (tests/test_gpu_bvh.py); a ray that starts exactly in the plane of a triangle whose box it does not reach is the one documented exception (RT_OPT_USE_BVH in include/rt_abi.h)"}
+                "in_plane_origin_scan": "on" if sb["bvh_plane_guard"] else "off (the calibration frame found no ray that needs it)",
+                "note": "frames byte-identical to brute force (tests/test_gpu_bvh.py); the in-plane-origin hit that no box hierarchy finds "
+                        "(raytracer.cpp:319-321) is covered by a scan behind the traversals, kept only when a calibration frame of "
+                        "this scene and camera shows a ray that takes that branch (RT_OPT_BVH_PLANE_GUARD in include/rt_abi.h)"}
 
     rays_local = st_timed["rays_primary"] + st_timed["rays_reflect"] + st_timed["rays_shadow"]
     if world > 1:

@@ -15,6 +15,7 @@ RT_OPT_BOUNDING_TESTS = 8
 RT_OPT_WORK_COUNTERS = 9
 RT_OPT_SCAN_COPIES = 10
 RT_OPT_FRAMES_IN_FLIGHT = 11
+RT_OPT_BVH_PLANE_GUARD = 12
 SCAN_KINDS = ["plain_nearest", "camera", "shadow_point", "shadow_directional", "reflection", "plain_shadow"]
 
 
@@ -64,7 +65,7 @@ class RtStats(C.Structure):
         ("closest_launches", C.c_uint32), ("anyhit_launches", C.c_uint32), ("exact_launches", C.c_uint32),
         ("n_triangles", C.c_int32), ("n_spheres", C.c_int32), ("n_groups", C.c_int32),
         ("n_irregular", C.c_int32), ("filter_form", C.c_int32),
-        ("camera_ms", C.c_double), ("camera_launches", C.c_uint32), ("reserved", C.c_uint32),
+        ("camera_ms", C.c_double), ("camera_launches", C.c_uint32), ("bvh_plane_guard", C.c_uint32),
         ("scan_work", RtScanWork * 6), ("scan_ms", C.c_double * 6), ("scan_launches", C.c_uint32 * 6),
     ]
 

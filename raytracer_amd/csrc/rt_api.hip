@@ -183,6 +183,7 @@ struct Lane {
     hipEvent_t in = nullptr, done = nullptr;   // the caller's stream at the time of the call / the call's last kernel
     bool pending = false;                      // `done` was recorded and nobody has waited for all of it yet
     unsigned long long seq = 0;                // number of the render call that recorded `done`
+    uint32_t* frame = nullptr;                 // the frame buffer that call writes
     DevBuf<int> bvh_spill;
     DevBuf<unsigned long long> bvh_tally;
 };
@@ -230,12 +231,12 @@ struct rt_ctx {
     int lane_queues = 0;                  // how many different ones
     int caller_queue = -1;                // the queue the caller's stream sat on when the lanes were made (-1: not known)
     Lane* cur = nullptr;                  // the lane of the call being enqueued (null: the context's own resources)
-    // `done` of the previous call in flight and the frame it wrote: a call that writes the same buffer runs its
-    // folds behind it, so that pixels land in call order.  (Calls that write different buffers are not tied to each
-    // other; measured, tying them costs nothing either.)
+    // (`done` of the previous call in flight: kept for the bookkeeping of sync_all)
     hipEvent_t prev_done = nullptr;
     uint32_t* prev_frame = nullptr;
     unsigned long long seq = 0;           // render calls issued in lanes so far
+    // LBVH tallies of lanes that have been released (rt_get_stats adds them; rt_reset_stats clears them)
+    unsigned long long tally_carry[3] = {0, 0, 0};
 
     // host copies kept so that the filter form can be switched after the upload
     std::vector<HostTri> h_tris;          // in Scene::objects order (triangles only)
@@ -259,6 +260,17 @@ struct rt_ctx {
     DevBuf<float> cl_camera, cl_lights, cl_sphere, cl_normal;
     DevBuf<int32_t> graze_slots, graze_start;   // per light: the triangles a shadow ray can graze (see TraceArgs)
     int n_clusters = 0;
+    // RT_OPT_BVH_PLANE_GUARD: behind every LBVH traversal, the scan that asks the in-plane-origin question alone.
+    // Mode 2 (default) decides once per context, when the LBVH is first switched on: the frame's rays are the same
+    // in every render call (camera, size and depth belong to the scene), so one whole frame traced with the scan on
+    // tells whether any pair of it takes that branch at all; only then is the scan kept.
+    int bvh_guard_mode = 2;
+    int bvh_guard = 1;                    // the scan runs (mode 1, or mode 2 after a calibration frame that found such pairs)
+    bool bvh_guard_calibrated = false;
+    unsigned long long bvh_guard_found = 0;   // in-plane-origin pairs of the calibration frame
+    double bvh_guard_calibration_s = 0;
+    int n_eye_plane = 0;                  // regular triangles in whose plane the eye may lie (FP32 bound): the camera rays' candidates
+    size_t n_graze = 0;                   // entries of all lights' graze lists: the shadow rays' candidates
     int n_regular_real = 0;               // regular triangles without the copies that fill up the axis ranges
     int pretest_any = 1;                  // ... and whether those are used
     int pretest = 1;                      // bounding-volume tests in front of the FP32 triangle test
@@ -599,6 +611,14 @@ int sync_all(rt_ctx* c) {
 }
 
 void drop_lanes(rt_ctx* c) {
+    // (what the lanes' traversals have counted since the last reset stays in the statistics)
+    for (Lane* L : c->lanes) {
+        if (!L->bvh_tally.p) continue;
+        std::vector<unsigned long long> tally(L->bvh_tally.n);
+        if (hipMemcpy(tally.data(), L->bvh_tally.p, tally.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) continue;
+        for (size_t b = 0; b + 3 < tally.size(); b += 4)
+            for (int k = 0; k < 3; k++) c->tally_carry[k] += tally[b + k];
+    }
     for (Lane* L : c->lanes) release_lane(L);
     c->lanes.clear();
     c->prev_done = nullptr;
@@ -710,6 +730,7 @@ int launch_trace(rt_ctx* c, const Workspace& W, TraceArgs A, hipStream_t st, siz
     const bool work = c->work_counters && c->work.p;
     A.work = work ? c->work.p : nullptr;
     HIP_TRY(hipMemsetAsync(W.ray_flags[MODE], 0, std::min(W.ray_flags_n[MODE], max_rays + RT_FLAGS_HEADER), st));   // (no queue of the pass is longer)
+    bool guard_scan = false;              // LBVH mode: the in-plane-origin scan ran and listed pairs
     if (!c->force_exact && c->hs.n_regular > 0) {
         int scan_kind = MODE == 0 ? 0 : 5;
         if (!c->use_bvh) {
@@ -729,6 +750,35 @@ int launch_trace(rt_ctx* c, const Workspace& W, TraceArgs A, hipStream_t st, siz
             ba.tally = tally + (size_t)MODE * (size_t)c->aux_grid * 4;
             if (c->use_bvh != 2) hipLaunchKernelGGL((k_bvh_trace<MODE, true>), dim3(c->aux_grid), dim3(RT_BVH_BLOCK), 0, st, dsc, ba, A);
             else hipLaunchKernelGGL((k_bvh_trace<MODE, false>), dim3(c->aux_grid), dim3(RT_BVH_BLOCK), 0, st, dsc, ba, A);
+            // The one hit no box hierarchy finds: a ray that starts exactly in the plane of a triangle and grazes it
+            // "hits" it at its own origin wherever the triangle is (raytracer.cpp:319-321).  The bounded scan's own
+            // machinery for that question -- camera rays: the triangles the host found the eye's plane distance too
+            // small for; shadow rays: the lights' graze lists; reflection rays: clusters whose normal cone and sphere
+            // admit such a plane -- lists the candidates, k_exact_pairs (below) decides them.
+            guard_scan = c->bvh_guard && ((MODE == 0 && camera_rays) ? c->n_eye_plane > 0
+                                          : MODE == 0 ? c->sphere_any.n > 0 : (c->n_graze > 0 && c->bound_lights.n > 0));
+            if (guard_scan) {
+                TraceArgs GA = A;
+                GA.in_plane_only = 1;
+                GA.shared_origin_a = (MODE == 0 && camera_rays) ? c->eye_a.p : nullptr;
+                GA.shared_dir_rinv = (MODE == 1 && c->dir_rinv.n > 0) ? c->dir_rinv.p : nullptr;
+                GA.cone_camera = (MODE == 0 && camera_rays) ? c->cone_camera.p : nullptr;
+                GA.sphere_any = (MODE == 0 && !camera_rays) ? c->sphere_any.p : nullptr;
+                GA.plane_any = c->plane_any.p;
+                GA.bound_lights = MODE == 1 ? c->bound_lights.p : nullptr;
+                GA.light_frame = MODE == 1 ? c->light_frame.p : nullptr;
+                const dim3 grid(std::max(1, c->filter_grid[MODE][0][1][0] / (c->cur ? c->beside_grid_div : 1))), block(RT_BLOCK);
+                const v16f* records = (const v16f*)c->tri_filt.p;
+#define RT_LAUNCH_GUARD(M, R, CN)                                                                                    \
+                do {                                                                                                  \
+                    if (c->robust) hipLaunchKernelGGL((k_filter<M, R, true, CN, false>), grid, block, 0, st, dsc, records, GA);   \
+                    else hipLaunchKernelGGL((k_filter<M, R, false, CN, false>), grid, block, 0, st, dsc, records, GA);             \
+                } while (0)
+                if (MODE == 0 && camera_rays) RT_LAUNCH_GUARD(0, RT_RPL_SHARED, 1);
+                else if (MODE == 0) RT_LAUNCH_GUARD(0, RT_RPL_ANY, 4);
+                else RT_LAUNCH_GUARD(1, RT_RPL_SHARED, 2);
+#undef RT_LAUNCH_GUARD
+            }
         } else {
             const dim3 block(RT_BLOCK);
             const v16f* records = (const v16f*)c->tri_filt.p;
@@ -753,7 +803,7 @@ int launch_trace(rt_ctx* c, const Workspace& W, TraceArgs A, hipStream_t st, siz
         t.stop();
     }
     Timed t(c, st, RT_WORK_KINDS, events);
-    if (!c->force_exact && c->hs.n_regular > 0 && !c->use_bvh) {      // (the LBVH traversal lists no pairs)
+    if (!c->force_exact && c->hs.n_regular > 0 && (!c->use_bvh || guard_scan)) {      // (the LBVH traversal itself lists no pairs)
         hipLaunchKernelGGL(k_exact_pairs<MODE>, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, dsc,
                            (const TriExact*)c->tri_exact.p, A);
         HIP_TRY(hipGetLastError());
@@ -930,8 +980,6 @@ int run_pass(rt_ctx* c, const Workspace& ws, PassDesc pd, int nrows, hipStream_t
     }
     // the fold (and whatever the caller enqueues next) comes after everything on the side stream
     if (overlap) HIP_TRY(hipStreamWaitEvent(st, ev_phong[levels - 1], 0));
-    // ... and, with several calls in flight, after the folds of the call before this one: pixels land in call order
-    if (c->cur && c->prev_done && c->prev_frame == c->frame) HIP_TRY(hipStreamWaitEvent(st, c->prev_done, 0));
     for (int k = levels - 1; k >= 0; k--) {
         FoldArgs fa{};
         fa.sc = dsc; fa.lvl = level_of(ws, k); fa.parent_lvl = level_of(ws, k > 0 ? k - 1 : 0);
@@ -990,6 +1038,12 @@ int render_rows(rt_ctx* c, int y_start, int tile_rows, int stride_rows, int n_ti
         HIP_TRY(hipEventRecord(L->in, st));
         HIP_TRY(hipStreamWaitEvent(L->main, L->in, 0));
     }
+    // A call that writes a buffer another call in flight writes runs wholly behind that call: it clears its pixels
+    // before it traces them, and a reader that has joined the earlier call must not see them go black.  (A caller
+    // that pipelines frames binds one buffer per call in flight and meets none of these waits.)
+    for (Lane* other : c->lanes)
+        if (other != L && other->pending && other->frame == c->frame) HIP_TRY(hipStreamWaitEvent(L->main, other->done, 0));
+    L->frame = c->frame;
     const int rows_per_pass = (int)(L->ws.cap / W);
     c->last_stream = st;
     c->cur = L;
@@ -1218,6 +1272,10 @@ int install_filter(rt_ctx* c, int robust) {
                 }
             });
         }
+        c->n_eye_plane = 0;
+        for (const Group& G : groups)
+            for (int k = G.fax[0]; k < G.fax[3]; k++)
+                if (!exact[(size_t)k].hole && !(std::fabs(eye_a[(size_t)k]) > G.q[0].a_zero)) c->n_eye_plane++;
         // Per light (shadow rays meet the untransformed triangles in world space, raytracer.cpp:553):
         // point light: cone from the light, and the light's distance from the triangle's plane;
         // directional light: disc in the plane perpendicular to the light's direction, coordinates
@@ -1423,6 +1481,7 @@ int install_filter(rt_ctx* c, int robust) {
             }
             HIP_TRY(c->cl_sphere.upload(cl_sphere)); HIP_TRY(c->cl_normal.upload(cl_normal)); HIP_TRY(c->cl_camera.upload(cl_cam));
             for (size_t l = 0; l < NL; l++) graze_start[l * (NC + 1) + NC] = (int32_t)((l + 1 < NL) ? graze_start[(l + 1) * (NC + 1)] : (int32_t)graze_slots.size());
+            c->n_graze = graze_slots.size();
             graze_slots.push_back(0);                        // (never empty)
             HIP_TRY(c->cl_lights.upload(cl_lights)); HIP_TRY(c->graze_slots.upload(graze_slots)); HIP_TRY(c->graze_start.upload(graze_start));
         }
@@ -1889,6 +1948,42 @@ static int upload_scene(rt_ctx** out, const rt_scene_desc* d) {
 
 extern "C" {
 
+// RT_OPT_BVH_PLANE_GUARD = 2: one whole frame through the LBVH with the in-plane-origin scan behind every traversal,
+// into the context's own frame buffer, its counts kept out of the statistics.  The scan stays on iff some pair of that
+// frame took the in-plane-origin branch of Triangle::intersection (raytracer.cpp:319-321).
+static int calibrate_bvh_guard(rt_ctx* c) {
+    if (c->bvh_guard_mode != 2) { c->bvh_guard = c->bvh_guard_mode; return 0; }
+    if (c->bvh_guard_calibrated) { c->bvh_guard = c->bvh_guard_found ? 1 : 0; return 0; }
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipDeviceSynchronize());
+    DevCounters before;
+    HIP_TRY(hipMemcpy(&before, c->counters.p, sizeof before, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> tally(2 * (size_t)c->aux_grid * 4);
+    HIP_TRY(hipMemcpy(tally.data(), c->bvh_tally.p, tally.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    uint32_t* const frame = c->frame;
+    const int in_flight = c->in_flight, profile = c->profile, work = c->work_counters, use = c->use_bvh, exact = c->force_exact;
+    c->frame = c->own_frame.p; c->in_flight = 1; c->profile = 0; c->work_counters = 0; c->force_exact = 0;
+    c->use_bvh = 1; c->bvh_guard = 1;
+    int rc = render_rows(c, 0, c->hs.height, c->hs.height, 1, nullptr);
+    hipError_t e = hipDeviceSynchronize();
+    c->frame = frame; c->in_flight = in_flight; c->profile = profile; c->work_counters = work; c->use_bvh = use; c->force_exact = exact;
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("LBVH calibration frame: ") + hipGetErrorString(e));
+    DevCounters after;
+    HIP_TRY(hipMemcpy(&after, c->counters.p, sizeof after, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(c->counters.p, &before, sizeof before, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->bvh_tally.p, tally.data(), tally.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(c->own_frame.p, 0, (size_t)c->hs.width * c->hs.height * 4));
+    c->bvh_guard_found = after.in_plane_origin_hits - before.in_plane_origin_hits;
+    c->bvh_guard_calibrated = true;
+    c->bvh_guard = c->bvh_guard_found ? 1 : 0;
+    c->bvh_guard_calibration_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (std::getenv("RT_GUARD_REPORT"))
+        fprintf(stderr, "LBVH in-plane-origin scan: calibration frame found %llu such pairs in %.3f s: scan %s\n",
+                c->bvh_guard_found, c->bvh_guard_calibration_s, c->bvh_guard ? "on" : "off");
+    return 0;
+}
+
 int rt_set_option(rt_ctx* c, int option, int64_t value) {
     if (!c) return fail(RT_ERR_ARG, "rt_set_option: null ctx");
     RT_GUARD_BEGIN
@@ -1927,10 +2022,19 @@ int rt_set_option(rt_ctx* c, int option, int64_t value) {
             c->in_flight = (int)value;
             return 0;
         }
+        case RT_OPT_BVH_PLANE_GUARD:
+            if (value < 0 || value > 2) return fail(RT_ERR_ARG, "rt_set_option: the LBVH's in-plane-origin scan is 0 (off), 1 (on) or 2 (decided by a calibration frame)");
+            c->bvh_guard_mode = (int)value;
+            c->bvh_guard = value == 2 ? 1 : (int)value;
+            if (c->use_bvh) return calibrate_bvh_guard(c);
+            return 0;
         case RT_OPT_BOUNDING_TESTS: c->pretest = value ? 1 : 0; c->pretest_any = value == 1 ? 1 : 0; return 0;
         case RT_OPT_USE_BVH:
             if (value) {
+                HIP_TRY(hipSetDevice(c->device));
                 int rc = build_bvh(c);
+                if (rc) return rc;
+                rc = calibrate_bvh_guard(c);
                 if (rc) return rc;
             }
             c->use_bvh = value == 2 ? 2 : (value ? 1 : 0);      // 1: four-wide nodes, 2: the binary tree they are made from
@@ -1971,6 +2075,7 @@ int rt_join(rt_ctx* c, void* stream, int keep_latest) {
 
 int rt_render_tile_noalloc(rt_ctx* c, int y0, int rows, void* stream) {
     if (!c) return fail(RT_ERR_ARG, "rt_render_tile_noalloc: null ctx");
+    RT_GUARD_BEGIN
     if (rows < 0 || y0 < 0 || (long long)y0 + rows > c->hs.height)
         return fail(RT_ERR_RANGE, "rt_render_tile_noalloc: rows outside the frame");
     if (rows == 0) return 0;
@@ -2000,10 +2105,14 @@ int rt_render_tile_noalloc(rt_ctx* c, int y0, int rows, void* stream) {
     // The array keeps whatever the previous call left in it, at whatever offsets that call's sizes
     // put it: the one slice that must start at zero (the count of finished blocks behind the
     // hit offsets) is cleared here; queue lengths, counters and flags are cleared by the pass.
+    // (calls still in flight in lanes come first: pixels land in call order; a wait allocates nothing)
+    for (Lane* L : c->lanes)
+        if (L->pending) HIP_TRY(hipStreamWaitEvent(st, L->done, 0));
     HIP_TRY(hipMemsetAsync(ws.hit_offsets, 0, ((size_t)c->aux_grid + 1) * sizeof(uint32_t), st));
     c->last_stream = st;
     PassDesc pd{y0, rows, rows, 0};
     return run_pass(c, ws, pd, rows, st, /*side_work=*/false);
+    RT_GUARD_END("rt_render_tile_noalloc")
 }
 
 int rt_primary_hits(rt_ctx* c, int y0, int rows, uint64_t* keys, size_t count) {
@@ -2203,11 +2312,12 @@ int rt_get_stats(rt_ctx* c, rt_stats* out) {
             }
         }
     }
+    out->bvh_node_tests += c->tally_carry[0]; out->bvh_leaf_tests += c->tally_carry[1]; out->exact_tests += c->tally_carry[2];
     out->in_plane_origin_hits = dc.in_plane_origin_hits; out->flagged_rays = dc.flagged_rays;
     out->closest_ms = c->ms[0] + c->ms[1] + c->ms[4]; out->anyhit_ms = c->ms[2] + c->ms[3] + c->ms[5];
     out->closest_launches = c->launches[0] + c->launches[1] + c->launches[4];
     out->anyhit_launches = c->launches[2] + c->launches[3] + c->launches[5];
-    out->camera_ms = c->ms[1]; out->camera_launches = c->launches[1]; out->reserved = 0;
+    out->camera_ms = c->ms[1]; out->camera_launches = c->launches[1]; out->bvh_plane_guard = (c->use_bvh && c->bvh_guard) ? 1u : 0u;
     out->exact_ms = c->ms[RT_WORK_KINDS]; out->exact_launches = c->launches[RT_WORK_KINDS];
     static_assert(RT_WORK_KINDS == RT_SCAN_KINDS && sizeof(rt_scan_work) == RT_WORK_FIELDS * sizeof(uint64_t), "scan work layout");
     HIP_TRY(hipMemcpy(out->scan_work, c->work.p, sizeof out->scan_work, hipMemcpyDeviceToHost));
@@ -2224,6 +2334,7 @@ int rt_reset_stats(rt_ctx* c) {
     { int rc = sync_all(c); if (rc) return rc; }
     drain_spans(c);
     for (int k = 0; k <= RT_WORK_KINDS; k++) { c->ms[k] = 0; c->launches[k] = 0; }
+    for (int k = 0; k < 3; k++) c->tally_carry[k] = 0;
     HIP_TRY(hipMemset(c->counters.p, 0, sizeof(DevCounters)));
     HIP_TRY(hipMemset(c->work.p, 0, RT_WORK_KINDS * RT_WORK_FIELDS * sizeof(unsigned long long)));
     if (c->bvh_tally.p) HIP_TRY(hipMemset(c->bvh_tally.p, 0, 2 * (size_t)c->aux_grid * 4 * sizeof(unsigned long long)));

@@ -252,6 +252,11 @@ struct TraceArgs {
     const float4* shadow_scan;
     uint32_t shadow_stride;
     unsigned long long* work;            // k_filter<..., WORK = true>: [RT_WORK_KINDS][RT_WORK_FIELDS] executed-work counters
+    // 1: the bounded instances ask ONLY the in-plane-origin question (raytracer.cpp:319-321) -- no reach question at
+    // any level -- and list the pairs it names: the complement of a box hierarchy, which finds every hit but that one
+    // (a hit "at the ray's own origin" on a triangle whose box the ray never reaches).  Launched behind the LBVH
+    // traversal; what it lists goes through k_exact_pairs like any other pair.
+    int32_t in_plane_only;
 };
 
 // Executed work of the scans, counted per wave in registers and added to TraceArgs::work at the
@@ -746,7 +751,11 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
     // Can the task's cone of directions from the shared point (PRE 1, 2) reach the cone `rec` (unit axis, cosine)
     // around a sphere?  Cones meet when the angle between their axes is at most the sum of their half-angles;
     // and the sphere's axis may leave the fan's plane by at most the two angles together.
+    const bool guard_only = A.in_plane_only != 0;          // (a kernel argument: wave-uniform)
     auto cone_reach = [&](const float4 rec) -> bool {
+        // (in-plane-origin question only, camera rays: the host marked the records of triangles -- and of clusters with
+        // such a member -- in whose plane the eye may lie with "every direction", cos = -2)
+        if (PRE == 1 && guard_only) return rec.w < -1.0f;
         float along = rec.x * guard.bx + rec.y * guard.by + rec.z * guard.bz;
         if (PRE == 2) along = fabsf(along);
         const float ct = rec.w, st = judge_sqrt(fmaxf(1.0f - ct * ct, 0.0f));
@@ -795,7 +804,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
             }
         } else {
             bool in_reach = j < cend;
-            if (guard.cull && j < cend) in_reach = (PRE == 3) ? disc_reach(rec) : cone_reach(rec);
+            if ((guard.cull || (PRE == 1 && guard_only)) && j < cend) in_reach = (PRE == 3) ? disc_reach(rec) : cone_reach(rec);
             out[1] = 0ull;                               // (the plane guard's answers are added afterwards, see below)
             out[0] = __ballot(in_reach);
         }
@@ -819,6 +828,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
             }
             return live;
         } else {
+            if (PRE == 1 && guard_only) return rec.w < -1.0f;
             if (!guard.cull) return true;
             return (PRE == 3) ? disc_reach(rec) : cone_reach(rec);
         }
@@ -874,7 +884,9 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                 }
             }
             // clusters first, one per lane (a chunk holds at most 64 and starts at a multiple of 64) ...
-            const unsigned long long cl_reach = __ballot(lane < n_grp && cluster_reach((cbeg >> 6) + lane));
+            // (in-plane-origin question only: nothing is asked about reach; shadow rays go by the graze lists below,
+            // reflection rays by cluster_named, camera rays by the records the host marked)
+            const unsigned long long cl_reach = (guard_only && PRE != 1) ? 0ull : __ballot(lane < n_grp && cluster_reach((cbeg >> 6) + lane));
             if (WORK) wk.v[RT_WK_CLUSTERS] += (unsigned int)n_grp;
             // ... then the triangles, one per lane, RT_GROUPS_AHEAD groups per round: of the clusters that
             // passed, and (reflection rays) of those a member of which could be named, for that question alone
@@ -1132,7 +1144,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                         }
                     }
 #pragma unroll
-                    for (int jb = 0; jb < RT_BATCH; jb++) wants[jb] = (low[jb] <= cones_cur[4 * jb + 3]) | (a_low[jb] <= fp.a_zero);
+                    for (int jb = 0; jb < RT_BATCH; jb++) wants[jb] = (!guard_only & (low[jb] <= cones_cur[4 * jb + 3])) | (a_low[jb] <= fp.a_zero);
                 }
                 bool any_wanted = named != 0;
 #pragma unroll
@@ -1298,6 +1310,13 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
             split = (int)((n_waves + n_ray_blocks - 1) / n_ray_blocks);
             if (split > finest) split = finest;
         }
+    }
+    // (a launch that asks the in-plane-origin question alone does little per triangle: one task per block of rays,
+    // cut further only while there are fewer blocks than waves)
+    if (CONE && A.in_plane_only) {
+        split = (int)((n_waves + n_ray_blocks - 1) / n_ray_blocks);
+        if (split > max_split) split = max_split;
+        if (split < 1) split = 1;
     }
     const unsigned int n_tasks = n_ray_blocks * (unsigned int)split;
     const int n_groups = sc->n_groups;

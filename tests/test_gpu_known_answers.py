@@ -152,10 +152,12 @@ def test_in_plane_origin_branch(oracle, tmp_path):
     """Triangle::intersection returns r = 0 / b -- a "hit" at the ray's own origin -- when the origin lies exactly in
     the triangle's plane (a == 0) and the ray grazes it (|b| < eps), wherever the triangle is (raytracer.cpp:319-321).
     Here the eye lies in the plane y = 0 of a triangle far outside the view: the scanlines next to the horizon
-    take that branch for every pixel and show that triangle instead of the sphere in front of the camera.  The
-    brute-force scan reproduces the oracle's frame and nearest hits and counts the events; a box hierarchy cannot
-    find such a hit (the documented limit of RT_OPT_USE_BVH), so the LBVH frame differs in exactly those pixels."""
+    take that branch for every pixel and show that triangle instead of the sphere in front of the camera.  Every
+    configuration must reproduce the oracle's frame and nearest hits -- the LBVH too, whose boxes the rays never
+    reach: the scan behind its traversal finds those pairs (RT_OPT_BVH_PLANE_GUARD); with that scan switched off
+    the LBVH differs in exactly those pixels, which is what the scan is for."""
     from raytracer_amd.render import Renderer
+    from tests.oracle_api import compare
     path = tmp_path / "in_plane.scene"
     path.write_text(IN_PLANE_SCENE)
     sc = Scene.load(str(path), 80, 80, 2)
@@ -165,7 +167,7 @@ def test_in_plane_origin_branch(oracle, tmp_path):
     # (the scanlines whose |dir.y| rounds below eps = 0.05f: two on either side of the horizon line y = 40, where
     # b = 0 makes r = 0 / 0 a NaN that is no hit, raytracer.cpp:525)
     assert rows == [38, 39, 41, 42] and (want_obj[rows] == 0).all() and (want_d[rows] == 0).all()
-    for label, opts in [c for c in CONFIGS if "USE_BVH" not in c[1]]:
+    for label, opts in CONFIGS + [("lbvh-binary", {"USE_BVH": 2})]:
         r = Renderer(sc)
         for key, value in opts.items():
             r.set_option(getattr(abi, "RT_OPT_" + key), value)
@@ -175,13 +177,83 @@ def test_in_plane_origin_branch(oracle, tmp_path):
         r.close()
         assert np.array_equal(obj, want_obj), label
         assert np.array_equal(d[want_obj >= 0].view(np.uint32), want_d[want_obj >= 0].view(np.uint32)), label
-        worst, ndiff, _ = __import__("tests.oracle_api", fromlist=["compare"]).compare(img, want)
+        worst, ndiff, _ = compare(img, want)
         assert worst <= 1 and ndiff <= 2, (label, worst, ndiff)
         if label != "exact":
             assert st["in_plane_origin_hits"] >= len(rows) * 80, label
     r = Renderer(sc)
     r.set_option(abi.RT_OPT_USE_BVH, 1)
+    r.set_option(abi.RT_OPT_BVH_PLANE_GUARD, 0)
     obj, _ = r.primary_hits()
     r.close()
     differs = obj != want_obj
     assert differs.any() and not differs[[y for y in range(80) if y not in rows]].any()
+
+
+# The same branch taken by shadow rays and by reflected rays.  Every number is chosen so that the reference's
+# arithmetic is exact: a 64 x 64 frame (u, v and 1 - u, 1 - v are exact floats), an image plane at x = 1 seen from
+# the origin (every camera direction is (1, y, z)), a mirror wall of two triangles in the plane x = 2 whose edge
+# cross products are powers of two (unit normal exactly (-1, 0, 0)): every hit point is (2, 2y, 2z) exactly.  A small
+# triangle in the same plane, a thousand units away, then has a == 0 for every ray that leaves the wall; the
+# reflected rays of the outer scanlines graze the plane (|b| = 1 / |(1, y, z)| < 0.05), and so does every shadow
+# ray towards the directional light and towards the point light from far enough: the reference lets the far
+# triangle (and the wall's other half) "hit" them at their own origin.
+IN_PLANE_SECONDARY_SCENE = """cam 0 0 0  1 -40 -1  1 -40 1  1 40 -1  1 40 1
+lta 0.3 0.3 0.3
+ltd 0.02 -1 0  0.7 0.7 0.7
+ltp 1.5 0 0  0.6 0.6 0.6
+mat 0.1 0.9 0.1  0.4 0.4 0.4  0 0 0  1  0 0 0
+tri 2 1000 0  2 1000 2  2 1002 0
+mat 0.2 0.2 0.9  0.5 0.5 0.5  0.2 0.2 0.2  4  0.5 0.5 0.5
+tri 2 -128 -128  2 -128 128  2 128 -128
+tri 2 128 128  2 128 -128  2 -128 128
+mat 0.9 0.2 0.2  0.5 0.5 0.5  0.3 0.3 0.3  8  0 0 0
+sph 1.2 0 0 0.2
+"""
+
+
+def test_in_plane_origin_branch_of_shadow_and_reflected_rays(oracle, tmp_path):
+    from raytracer_amd.render import Renderer
+    from tests.oracle_api import compare
+    path = tmp_path / "in_plane_secondary.scene"
+    path.write_text(IN_PLANE_SECONDARY_SCENE)
+    sc = Scene.load(str(path), 64, 64, 1)
+    hit0, point, refl, occl, hit1, d1 = oracle_bounce(oracle, sc)
+    on = hit0 >= 0
+    wall = (hit0 == 1) | (hit0 == 2)
+    # the construction works: wall hits lie exactly in the plane, the outer scanlines' reflected rays "hit" the far
+    # triangle (object 0) at distance 0, and the far triangle blocks shadow rays of wall points
+    assert wall.sum() > 3000 and (point[wall][:, 0] == 2.0).all()
+    far_hits = wall & (hit1 == 0)
+    assert far_hits.sum() > 1000 and (d1[far_hits] == 0).all()
+    assert (occl[wall][:, 0] & 1).all()                      # (the directional light grazes the wall everywhere)
+    sc2 = Scene.load(str(path), 64, 64, 2)
+    want, counts = oracle.render(sc2)
+    for label, opts in [c for c in CONFIGS if c[0] != "no-shared"] + [("lbvh-binary", {"USE_BVH": 2})]:
+        r = Renderer(sc)
+        for key, value in opts.items():
+            r.set_option(getattr(abi, "RT_OPT_" + key), value)
+        g_point, g_refl, g_occl, g_hit1, g_d1 = r.bounce_probe(sc.desc.n_lights)
+        r.close()
+        assert np.array_equal(g_point[on].view(np.uint64), point[on].view(np.uint64)), label
+        assert np.array_equal(g_occl[on], occl[on]), (label, int((g_occl[on] != occl[on]).sum()))
+        assert np.array_equal(g_hit1[on], hit1[on]), (label, int((g_hit1[on] != hit1[on]).sum()))
+        both = on & (hit1 >= 0)
+        assert np.array_equal(g_d1[both].view(np.uint32), d1[both].view(np.uint32)), label
+        r = Renderer(sc2)
+        for key, value in opts.items():
+            r.set_option(getattr(abi, "RT_OPT_" + key), value)
+        r.render_frame()
+        img, st = r.download(), r.stats()
+        r.close()
+        worst, ndiff, _ = compare(img, want)
+        assert worst <= 1 and ndiff <= 2, (label, worst, ndiff)
+        for key in ("rays_reflect", "rays_shadow", "hits"):
+            assert st[key] == counts[key], (label, key)
+    # without the scan behind the traversal the LBVH misses exactly such hits
+    r = Renderer(sc)
+    r.set_option(abi.RT_OPT_USE_BVH, 1)
+    r.set_option(abi.RT_OPT_BVH_PLANE_GUARD, 0)
+    _, _, g_occl, g_hit1, _ = r.bounce_probe(sc.desc.n_lights)
+    r.close()
+    assert (g_hit1[on] != hit1[on]).any() or (g_occl[on] != occl[on]).any()

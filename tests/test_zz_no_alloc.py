@@ -88,3 +88,35 @@ def test_noalloc_rejects_a_tile_beyond_the_static_workspace():
     r.close()
     want, _ = render(sc, 1000, rows, noalloc=False)
     assert np.array_equal(got, want)
+
+
+def test_noalloc_call_leaves_device_memory_as_it_found_it():
+    """What the entry point exists for: between the moment the call is made and the moment its work has finished,
+    the device's free memory does not move (no hipMalloc / hipFree, no workspace growth) -- also with event timing
+    requested (RT_OPT_PROFILE), which the allocating entry point serves by creating events."""
+    import ctypes as C
+    from raytracer_amd.render import Renderer
+    from tests.test_gpu_in_flight import Hip
+    hip = Hip()
+    hip.lib.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    hip.lib.hipDeviceSynchronize.argtypes = []
+
+    def free_bytes():
+        free, total = C.c_size_t(), C.c_size_t()
+        hip.ok(hip.lib.hipDeviceSynchronize())
+        hip.ok(hip.lib.hipMemGetInfo(C.byref(free), C.byref(total)))
+        return free.value
+
+    sc = Scene.load(scene_file("teapot"), 192, 108, 5)
+    want, _ = render(sc, 0, 108, noalloc=False)
+    for profile in (0, 1):
+        r = Renderer(sc)
+        r.set_option(abi.RT_OPT_PROFILE, profile)
+        r.render_tile_noalloc(0, 54)             # (warm-up: code objects are loaded at a kernel's first launch)
+        before = free_bytes()
+        r.render_tile_noalloc(0, 108)
+        r.render_tile_noalloc(20, 30)
+        after = free_bytes()
+        assert after == before, (profile, before - after)
+        assert np.array_equal(r.download(), want)
+        r.close()
