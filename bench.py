@@ -422,6 +422,10 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     st_timed = r.stats()
+    lane_deal = {"lanes": st_timed["lanes"], "hardware_queues_found": st_timed["lane_hw_queues_found"],
+                 "lanes_on_distinct_queues": "yes" if not st_timed["lanes_share_a_queue"] else "no",
+                 "callers_stream_on_a_queue_of_its_own": {0: "yes", 1: "no"}.get(st_timed["caller_stream_shares_a_queue"], "unknown"),
+                 "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}
     if args.dump_frame and rank == 0:
         import numpy as np
         np.save(args.dump_frame, pipe.last_frame().cpu().numpy())
@@ -625,6 +629,7 @@ def main():
                                                 "every frame is traced in full into a buffer of its own and exchanged, none is skipped "
                                                 "or reused; ms_per_step is time per frame at that throughput, one_frame_at_a_time_ms the "
                                                 "same K frames with one call in flight",
+                       "frames_in_flight_queues": lane_deal,
                        "triangles": n_tri, "spheres": n_sph, "lights": scene.desc.n_lights,
                        "tile_rows": args.tile_rows, "parallelism": f"interleaved scanline tiles x{world}",
                        "rays_per_frame": {"primary": n_primary // args.steps, "reflect": n_reflect // args.steps,

@@ -205,6 +205,15 @@ typedef struct rt_stats {
     double scan_ms[RT_SCAN_KINDS];           /* RT_OPT_PROFILE: summed duration of the scan launches by kind (a shadow
                                                 launch holds both kinds of light: booked under the kind of light 0) */
     uint32_t scan_launches[RT_SCAN_KINDS];
+    /* RT_OPT_FRAMES_IN_FLIGHT > 1, once a render call has set the calls' streams up: how they were dealt onto the
+       process's hardware queues (found by running short kernels on pairs of streams and comparing the device clock
+       intervals they note: streams on one queue run one after the other). */
+    uint32_t lanes;                       /* calls that can be in flight (0: none set up) */
+    uint32_t lane_hw_queues_found;        /* different hardware queues found among the streams tried */
+    int32_t lanes_share_a_queue;          /* 1: two of the calls' streams sit on one queue (they do not overlap) */
+    int32_t caller_stream_shares_a_queue; /* 1: the caller's stream sits on a queue a call in flight uses (what is enqueued
+                                             on it waits behind that call's kernels); 0: it has a queue to itself;
+                                             -1: not known (no lanes yet, or the stream was capturing) */
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;

@@ -67,6 +67,8 @@ class RtStats(C.Structure):
         ("n_irregular", C.c_int32), ("filter_form", C.c_int32),
         ("camera_ms", C.c_double), ("camera_launches", C.c_uint32), ("bvh_plane_guard", C.c_uint32),
         ("scan_work", RtScanWork * 6), ("scan_ms", C.c_double * 6), ("scan_launches", C.c_uint32 * 6),
+        ("lanes", C.c_uint32), ("lane_hw_queues_found", C.c_uint32), ("lanes_share_a_queue", C.c_int32),
+        ("caller_stream_shares_a_queue", C.c_int32),
     ]
 
     def as_dict(self):

@@ -206,3 +206,26 @@ def test_no_two_lanes_share_a_hardware_queue(tmp_path):
             assert len(sides) == k and len(set(mains + sides)) == 2 * k, res.stderr
         else:
             assert not sides, res.stderr
+
+
+def test_the_deal_of_the_lanes_is_in_the_statistics():
+    """rt_stats says how the calls in flight were dealt onto hardware queues (the probe compares device-clock
+    intervals noted by short kernels, so it does not depend on host timing): with HIP's default of four queues, up
+    to four lanes never share one; before any call has been made in lanes nothing is claimed."""
+    from raytracer_amd.render import Renderer
+    sc = Scene.load(os.path.join(ROOT, "scenes", "mixed_xf.scene"), 160, 120, 3)
+    r = Renderer(sc)
+    r.render_frame()
+    st = r.stats()
+    assert st["lanes"] == 0 and st["caller_stream_shares_a_queue"] == -1
+    for k in (2, 3, 4):
+        r.set_option(abi.RT_OPT_FRAMES_IN_FLIGHT, k)
+        for _ in range(k + 1):
+            r.render_frame()
+        st = r.stats()
+        assert st["lanes"] == k
+        assert st["lane_hw_queues_found"] >= 2
+        if st["lane_hw_queues_found"] >= k:
+            assert st["lanes_share_a_queue"] == 0
+        assert st["caller_stream_shares_a_queue"] in (0, 1)
+    r.close()

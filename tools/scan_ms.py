@@ -20,15 +20,17 @@ torch.cuda.synchronize()
 frame = (time.perf_counter() - t0) / n * 1e3
 # ... and with four render calls in flight (RT_OPT_FRAMES_IN_FLIGHT)
 r.set_option(abi.RT_OPT_FRAMES_IN_FLIGHT, 4)
-for _ in range(4):
-    r.render_frame()
+frames = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in range(4)]      # (a buffer per call in flight)
+for i in range(4):
+    r.bind_frame(frames[i % 4]); r.render_frame()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for _ in range(4 * n):
-    r.render_frame()
+for i in range(4 * n):
+    r.bind_frame(frames[i % 4]); r.render_frame()
 torch.cuda.synchronize()
 frame3 = (time.perf_counter() - t0) / (4 * n) * 1e3
 r.set_option(abi.RT_OPT_FRAMES_IN_FLIGHT, 1)
+r.bind_frame(None)
 r.reset_stats()
 r.set_option(abi.RT_OPT_PROFILE, 1)
 for _ in range(n):
@@ -36,5 +38,14 @@ for _ in range(n):
 st = r.stats()
 ms = {k: round(v / n, 3) for k, v in st["scan_ms"].items() if v}
 ms["exact"] = round(st["exact_ms"] / n, 3)
-print(json.dumps({"lib": os.path.basename(os.environ.get("RAYTRACER_AMD_LIB", "default")), "frame_ms": round(frame, 3), "frame_ms_4_in_flight": round(frame3, 3), "ms": ms,
+work = None
+if os.environ.get("WORK"):
+    # one more frame through the counting instances: executed work per kind of scan
+    r.set_option(abi.RT_OPT_PROFILE, 0)
+    r.reset_stats()
+    r.set_option(abi.RT_OPT_WORK_COUNTERS, 1)
+    r.render_frame()
+    sw = r.stats()["scan_work"]
+    work = {k: {f: v[f] for f in ("tasks", "clusters", "groups", "groups_live", "batches", "batches_tested", "listed")} for k, v in sw.items() if v["tasks"]}
+print(json.dumps({"order": os.environ.get("RAYTRACER_AMD_SLOT_ORDER", "curve"), "work": work, "lib": os.path.basename(os.environ.get("RAYTRACER_AMD_LIB", "default")), "frame_ms": round(frame, 3), "frame_ms_4_in_flight": round(frame3, 3), "ms": ms,
                   "exact_tests": st["exact_tests"] // n}))
