@@ -96,9 +96,11 @@ def parse():
     ap.add_argument("--exchange", default="tiles", choices=["tiles", "packed"],
                     help="end-of-frame exchange for N > 1: one point-to-point transfer per tile straight into rank 0's "
                          "frame rows (tiles), or one per peer through a packed buffer (packed); same bytes either way")
-    ap.add_argument("--frames-in-flight", type=int, default=4,
-                    help="render calls in flight in the timed region (RT_OPT_FRAMES_IN_FLIGHT, 1..4): frame i+1 is traced "
-                         "beside the deep levels of frame i, each in a frame buffer of its own; 1 = one frame at a time")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="render calls in flight in the timed region (RT_OPT_FRAMES_IN_FLIGHT, 1..8): frame i+1 is traced "
+                         "beside the deep levels of frame i, each in a frame buffer of its own; 1 = one frame at a time; "
+                         "0 (default) = 4, or 8 from four ranks on (a rank's share of the frame is a chain of short launches: "
+                         "one rank's eighth of the 4K frame takes 1.15 ms per frame with 4 in flight, 1.03 with 8)")
     ap.add_argument("--dump-frame", default=None,
                     help="rank 0 writes the last frame of the timed region (after its exchange) to this .npy file")
     ap.add_argument("--no-overlap", action="store_true",
@@ -347,18 +349,15 @@ def config5_leg(job, args, steps, in_flight):
     return out
 
 
-def measured_traffic(mode, bounding_test):
-    """HBM bytes per launch of one scan kernel from the committed PMC passes of this same command
-    (profiles/*pmc_summary.csv, written by tools/pmc_passes.sh + tools/pmc_summary.py):
-    FETCH_SIZE is in KiB and reads half the bytes of a wide stream on gfx950 (doubled here),
-    WRITE_SIZE is in KiB and exact; both are sums over the DISPATCHES launches of one pass.
-    The kernel is k_filter<MODE, rays per lane, form, bounding test, counting> with counting = false.
-    None when no such file or kernel exists."""
+def pmc_of_kernel(mode, bounding_test):
+    """The committed PMC passes of this same command (profiles/*pmc_summary.csv, written by tools/pmc_passes.sh +
+    tools/pmc_summary.py), for the scan kernel k_filter<MODE, rays per lane, form, bounding test, counting = false>:
+    (file name, {counter: sum over the DISPATCHES launches of one pass}).  (None, {}) when there is no such file or kernel."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.csv")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.csv")), key=os.path.getmtime)
     if not files:
-        return None
+        return None, {}
     got = {}
     for r in csv.DictReader(open(files[-1])):
         name = r["kernel"].replace(" ", "")
@@ -367,9 +366,32 @@ def measured_traffic(mode, bounding_test):
         targs = name[len("k_filter<"):-1].split(",")
         if len(targs) == 5 and targs[0] == str(mode) and targs[3] == str(bounding_test) and targs[4] == "false":
             got[r["counter"]] = float(r["sum_over_dispatches"])
+    return os.path.basename(files[-1]), got
+
+
+def measured_traffic(mode, bounding_test):
+    """HBM bytes per launch of that kernel from those passes: FETCH_SIZE is in KiB and reads half the bytes of a wide
+    stream on gfx950 (doubled here), WRITE_SIZE is in KiB and exact.  None when the passes do not hold them."""
+    _, got = pmc_of_kernel(mode, bounding_test)
     if not all(k in got for k in ("FETCH_SIZE", "WRITE_SIZE", "DISPATCHES")) or got["DISPATCHES"] <= 0:
         return None
     return (2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024.0 / got["DISPATCHES"]
+
+
+def pmc_occupancy(mode, bounding_test, kernel_ms_avg, clock_khz, n_cu):
+    """How full the chip was while that kernel ran, from the same passes and THIS run's average launch duration:
+    waves resident per SIMD (SQ_WAVE_CYCLES counts in units of 4 cycles, summed over waves) and the share of SIMD
+    cycles in which a vector instruction executed (SQ_ACTIVE_INST_VALU, same unit), over n_cu x 4 SIMDs x clock x
+    duration; SQ_WAIT_ANY / SQ_WAVE_CYCLES is the share of a resident wave's time spent waiting."""
+    name, got = pmc_of_kernel(mode, bounding_test)
+    need = ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "DISPATCHES")
+    if not all(k in got for k in need) or got["DISPATCHES"] <= 0 or not clock_khz or kernel_ms_avg <= 0:
+        return None
+    simd_cycles = n_cu * 4 * clock_khz * 1e3 * kernel_ms_avg * 1e-3
+    return {"source": f"profiles/{name} (counters of a separate rocprofv3 --pmc run of this command; durations from this run)",
+            "waves_per_simd": 4.0 * got["SQ_WAVE_CYCLES"] / got["DISPATCHES"] / simd_cycles,
+            "valu_busy": 4.0 * got["SQ_ACTIVE_INST_VALU"] / got["DISPATCHES"] / simd_cycles,
+            "wait_share_of_wave_cycles": got["SQ_WAIT_ANY"] / got["SQ_WAVE_CYCLES"] if got["SQ_WAVE_CYCLES"] else None}
 
 
 def main():
@@ -387,7 +409,7 @@ def main():
     r = Renderer(scene)
     if args.exact_only:
         r.set_option(abi.RT_OPT_EXACT_ONLY, 1)
-    in_flight = max(1, min(4, args.frames_in_flight))
+    in_flight = max(1, min(8, args.frames_in_flight)) if args.frames_in_flight > 0 else (8 if world >= 4 else 4)
     # one frame buffer per render call in flight: frame i is exchanged while frame i+1 is traced
     frames = [torch.zeros((args.height, args.width, 4), dtype=torch.uint8, device=dev) for _ in range(in_flight)]
     stream = job.stream
@@ -667,14 +689,35 @@ def main():
                      "shadow_rays": "k_filter<1, %d, form, 2> (shadow rays)" % 8}
             pmc_key = {"camera_rays": (0, 1), "reflection_rays": (0, 4), "shadow_rays": (1, 2)}
             dom_scan = max(names, key=lambda k: executed[k]["ms_per_step"])
+            # the same kernel by the per-unit formula (42 FLOP x every ray x triangle pair of its launches, no culling):
+            # more than the peak, because the bounding hierarchy decides most pairs without the triangle test
+            dom_ms = executed[dom_scan]["ms_per_step"]
+            nominal_frac = (executed[dom_scan]["nominal_pairs_per_step"] * flop_per_test / (dom_ms * 1e-3) / PEAK_FP32_VALU
+                            if dom_ms > 0 else None)
+            launches_per_step = {"camera_rays": sd["scan_launches"]["camera"], "reflection_rays": sd["scan_launches"]["reflection"],
+                                 "shadow_rays": sd["scan_launches"]["shadow_point"] + sd["scan_launches"]["shadow_directional"]}[dom_scan] / steps
+            rays_of = {"camera_rays": sd["rays_primary"], "reflection_rays": sd["rays_reflect"], "shadow_rays": sd["rays_shadow"]}[dom_scan] / steps
+            ray_bytes = {"camera_rays": 24.0, "reflection_rays": 48.0, "shadow_rays": 24.0}[dom_scan]
+            algorithmic_bytes = ((rays_of * ray_bytes + executed[dom_scan]["executed_per_step"]["pairs_listed"] * 8.0) / max(1.0, launches_per_step)
+                                 + n_tri * 96.0)
+            traffic = measured_traffic(*pmc_key[dom_scan]) if world == 1 else None
             roof.update({"kernel": names[dom_scan] + ": the scan kernel of the timed configuration with the largest share of "
                                                       "the frame; executed FP32 operations of its three stages (bundle judgement, "
                                                       "per-ray bounding test, triangle test) over its duration",
                          "achieved": executed[dom_scan]["executed_tflops"], "frac": executed[dom_scan]["frac_of_peak"],
+                         "nominal_frac": nominal_frac,
+                         "nominal_frac_note": "culled: 42 FLOP x (rays x triangles) of the kernel's launches over its duration, as if "
+                                              "every pair took the triangle test; above 1 because the bounding tests decide most pairs",
+                         "launches_per_step": launches_per_step, "kernel_ms_avg": dom_ms / max(1.0, launches_per_step),
                          # (the committed PMC pass is a 1-GPU run: its per-launch bytes describe N = 1 only)
-                         "traffic": measured_traffic(*pmc_key[dom_scan]) if world == 1 else None,
+                         "traffic": traffic,
                          "traffic_source": "HBM bytes per launch, replayed from the committed PMC summary under profiles/ "
                                            "(not measured in this run)",
+                         "algorithmic_bytes_per_launch": algorithmic_bytes,
+                         "algorithmic_bytes_note": "rays x 48 B (24 B for camera and shadow rays: one vector) + listed pairs x 8 B, per "
+                                                   "launch, + the triangle tables once (96 B per triangle)",
+                         "traffic_ratio": traffic / algorithmic_bytes if traffic and algorithmic_bytes else None,
+                         "pmc": pmc_occupancy(*pmc_key[dom_scan], dom_ms / max(1.0, launches_per_step), clock_khz, n_cu) if world == 1 else None,
                          "timed_configuration": executed})
         else:
             roof.update({"kernel": plain["kernel"], "achieved": plain["achieved"], "frac": plain["frac"]})

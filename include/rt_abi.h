@@ -139,7 +139,7 @@ typedef enum rt_option {
                                  reference exactly where a ray takes that branch on a triangle whose box it does not
                                  reach */
     RT_OPT_FRAMES_IN_FLIGHT = 11 /* 1 (default): a render call's work runs on the caller's stream (and the internal
-                                 stream of RT_OPT_OVERLAP, joined back before the call's last kernel).  2..4: that
+                                 stream of RT_OPT_OVERLAP, joined back before the call's last kernel).  2..8: that
                                  many render calls may be in flight at once: call i runs on internal streams of its
                                  own with workspace i mod N, behind the work that was on the caller's stream at the
                                  time of the call, and is NOT joined back -- rt_join does that.  The short launches

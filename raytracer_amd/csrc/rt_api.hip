@@ -113,6 +113,7 @@ template <class T> struct DevBuf {
 // loaded until the process ends, on every GPU it runs on, so that the call itself allocates
 // nothing.  Host code never uses the array's name as an address: rt_upload_scene resolves the
 // current device's copy once (hipGetSymbolAddress) and everything goes through that pointer.
+#define RT_MAX_FRAMES_IN_FLIGHT 8
 #define RT_SCRATCH_BYTES ((size_t)64 << 20)
 #define RT_SCRATCH_MAX_DEVICES 64
 static __device__ __align__(256) unsigned char scratch[RT_SCRATCH_BYTES];
@@ -144,6 +145,17 @@ struct HostTri {
     int xf, axis;
 };
 
+// Queue lengths of the last pass traced in a workspace, copied to pinned host memory behind that pass: the next
+// pass of the same size launches its streaming kernels (k_hit, k_phong, k_fold, k_exact_pairs, the LBVH traversal ...)
+// with grids sized for those lengths instead of for the largest queue the pass could have.  The frame's rays are the
+// same from call to call, so the lengths repeat; a hint that is stale or absent costs time, never pixels (every such
+// kernel walks its queue with a grid-stride loop).  A deep level holds a few per cent of the pixels: a full-size grid
+// there is thousands of blocks that start, find nothing and leave, while the other calls in flight wait for the slots.
+struct PassHint {
+    int n_pix;                     // pixels of the pass the counts belong to (written by the host when the copy is enqueued)
+    uint32_t counts[72];           // [levels + 2] queue lengths as the pass left them (all ones until a copy has landed)
+};
+
 // The per-pass workspace: queues, keys, per-level hit records, pair lists.  Every array is a
 // slice of ONE block of device memory (the context's own allocation, or the library's static
 // scratch array for the entry point that allocates nothing), cut by carve_workspace.
@@ -171,6 +183,7 @@ struct Workspace {
     // FP32 scan copies (RayQueue::scan, TraceArgs::shadow_scan); null when the workspace keeps none
     float* scan[2] = {nullptr, nullptr};               // [9][cap], beside rayq[i]
     float4* shadow_scan[2] = {nullptr, nullptr};       // [n_lights][cap], by level parity
+    PassHint* hint = nullptr;                          // pinned host memory (null: none kept, e.g. the static workspace)
 };
 
 // What one render call in flight owns (RT_OPT_FRAMES_IN_FLIGHT > 1): a workspace, the two streams of a pass,
@@ -187,6 +200,7 @@ struct Lane {
     int main_queue = -1, side_queue = -1;      // the hardware queues its streams were found on (side: -1 = none of its own)
     DevBuf<int> bvh_spill;
     DevBuf<unsigned long long> bvh_tally;
+    PassHint* hint = nullptr;
 };
 
 struct rt_ctx {
@@ -215,6 +229,8 @@ struct rt_ctx {
     // workspace, sized for `ws.cap` rays per pass: one allocation, cut by carve_workspace
     Workspace ws;
     DevBuf<unsigned char> ws_block;
+    PassHint* hint = nullptr;             // of the context's own workspace
+    int grid_hints = 1;                   // RAYTRACER_AMD_GRID_HINTS=0 in the environment switches them off (A/B runs)
     hipStream_t side_stream = nullptr;    // the shadow/Phong half of a level runs here
     std::vector<hipEvent_t> ev_hit, ev_phong;   // per level: k_hit done / k_phong done
     int overlap = 1;                      // RT_OPT_OVERLAP
@@ -230,7 +246,8 @@ struct rt_ctx {
     std::vector<hipStream_t> lane_streams;
     std::vector<int> lane_stream_queue;   // per stream: the hardware queue it was found to sit on (numbered as found)
     int lane_queues = 0;                  // how many different ones
-    int caller_queue = -1;                // the queue the caller's stream sat on when the lanes were made (-1: not known)
+    int caller_queue = -1;                // the queue the caller's stream sat on when the lanes were made (-1: none of those found, or not known)
+    bool caller_probed = false;           // ... it was tried against every queue found (false: the stream was capturing)
     Lane* cur = nullptr;                  // the lane of the call being enqueued (null: the context's own resources)
     // (`done` of the previous call in flight: kept for the bookkeeping of sync_all)
     hipEvent_t prev_done = nullptr;
@@ -428,6 +445,9 @@ int ensure_workspace(rt_ctx* c) {
     }
     Workspace w;
     carve_workspace(&w, c->ws_block.p, want, levels, c->hs.n_lights, c->aux_grid, 16, (size_t)1 << 20, true);
+    if (!c->hint && c->grid_hints && hipHostMalloc((void**)&c->hint, sizeof(PassHint), hipHostMallocDefault) != hipSuccess) { c->hint = nullptr; (void)hipGetLastError(); }
+    if (c->hint) std::memset(c->hint, 0xff, sizeof(PassHint));
+    w.hint = c->hint;
     // (the last entry of hit_offsets counts finished blocks and must start at zero)
     e = hipMemset(w.hit_offsets, 0, ((size_t)c->aux_grid + 1) * sizeof(uint32_t));
     if (e != hipSuccess) {
@@ -547,6 +567,7 @@ int probe_lane_streams_once(rt_ctx* c) {
 // A stream that is capturing a graph must not be given probe kernels: its queue stays unknown (-1).
 int probe_caller_queue(rt_ctx* c, hipStream_t st) {
     c->caller_queue = -1;
+    c->caller_probed = false;
     hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &capturing) != hipSuccess) { (void)hipGetLastError(); return 0; }
     if (capturing != hipStreamCaptureStatusNone) return 0;
@@ -564,6 +585,7 @@ int probe_caller_queue(rt_ctx* c, hipStream_t st) {
         if (side < 0) return side;
         if (side == 0) c->caller_queue = q;
     }
+    c->caller_probed = true;
     return 0;
 }
 
@@ -612,6 +634,7 @@ void release_lane(Lane* L) {
     for (auto e : L->ev_phong) (void)hipEventDestroy(e);
     if (L->in) (void)hipEventDestroy(L->in);
     if (L->done) (void)hipEventDestroy(L->done);
+    if (L->hint) (void)hipHostFree(L->hint);
     delete L;             // (the buffers release themselves; the streams belong to the context)
 }
 
@@ -682,6 +705,9 @@ int ensure_lanes(rt_ctx* c, hipStream_t caller) {
             return give_up(RT_ERR_DEVICE, std::string("workspace of ") + std::to_string(bytes >> 20) + " MiB for a frame in flight: " +
                                               hipGetErrorString(e) + " (lower RT_OPT_PASS_PIXELS or RT_OPT_FRAMES_IN_FLIGHT)");
         carve_workspace(&L->ws, L->block.p, want, levels, c->hs.n_lights, c->aux_grid, 16, (size_t)1 << 20, true);
+        if (c->grid_hints && hipHostMalloc((void**)&L->hint, sizeof(PassHint), hipHostMallocDefault) != hipSuccess) { L->hint = nullptr; (void)hipGetLastError(); }
+        if (L->hint) std::memset(L->hint, 0xff, sizeof(PassHint));
+        L->ws.hint = L->hint;
         e = hipMemset(L->ws.hit_offsets, 0, ((size_t)c->aux_grid + 1) * sizeof(uint32_t));
         if (e != hipSuccess) return give_up(RT_ERR_DEVICE, std::string("frames in flight: ") + hipGetErrorString(e));
         c->lanes.push_back(L);
@@ -713,10 +739,22 @@ struct Timed {
 
 // Nearest hit (MODE 0) or shadow (MODE 1) of one queue: filter, listed pairs, the rest.
 // `events`: false for the entry point that allocates nothing (event timing creates events).
+// Blocks for a kernel that streams `items` queue entries (four per thread), between one block per compute unit and
+// the full grid.
+int blocks_for(const rt_ctx* c, size_t items) {
+    const size_t blocks = (items + 4 * RT_BLOCK - 1) / (4 * RT_BLOCK);
+    return (int)std::min<size_t>((size_t)c->aux_grid, std::max<size_t>((size_t)c->n_cu, blocks));
+}
+
+// `est_rays`: how many rays the queue is expected to hold (a hint, see PassHint; max_rays when nothing is known).
 template <int MODE>
 int launch_trace(rt_ctx* c, const Workspace& W, TraceArgs A, hipStream_t st, size_t max_rays, bool camera_rays = false,
-                 bool events = true) {
+                 bool events = true, size_t est_rays = ~(size_t)0) {
     const DevScene* dsc = c->d_scene.p;
+    est_rays = std::min(est_rays, max_rays);
+    // (a queue longer than expected is still walked in full: by fewer threads)
+    const int ray_grid = blocks_for(c, 4 * est_rays + est_rays / 4);            // kernels with one ray per thread
+    const int pair_grid = blocks_for(c, 4 * est_rays + est_rays);               // the listed pairs: a few per ray, four per thread
     A.camera_rays = (MODE == 0 && camera_rays) ? 1 : 0;
     A.beside_others = c->cur ? 1 : 0;
     A.shared_origin_a = (MODE == 0 && camera_rays && c->shared_consts) ? c->eye_a.p : nullptr;
@@ -746,7 +784,9 @@ int launch_trace(rt_ctx* c, const Workspace& W, TraceArgs A, hipStream_t st, siz
     A.pair_seg = (unsigned int)(W.pair_cap[MODE] / A.pair_lists);
     const bool work = c->work_counters && c->work.p;
     A.work = work ? c->work.p : nullptr;
-    HIP_TRY(hipMemsetAsync(W.ray_flags[MODE], 0, std::min(W.ray_flags_n[MODE], max_rays + RT_FLAGS_HEADER), st));   // (no queue of the pass is longer)
+    // (no queue of the pass is longer than max_rays; beyond the expected length a flag may be left over from an earlier
+    // launch: such a ray takes the full reference-precision scan, which costs time, not pixels)
+    HIP_TRY(hipMemsetAsync(W.ray_flags[MODE], 0, std::min(W.ray_flags_n[MODE], std::min(max_rays, est_rays + est_rays / 4 + 4096) + RT_FLAGS_HEADER), st));
     bool guard_scan = false;              // LBVH mode: the in-plane-origin scan ran and listed pairs
     if (!c->force_exact && c->hs.n_regular > 0) {
         int scan_kind = MODE == 0 ? 0 : 5;
@@ -765,8 +805,8 @@ int launch_trace(rt_ctx* c, const Workspace& W, TraceArgs A, hipStream_t st, siz
             ba.spill = spill + (size_t)MODE * ((size_t)c->aux_grid * RT_BVH_BLOCK * RT_BVH_SPILL);   // one strip set per kind of query
             ba.counters = (BvhCounters*)&c->counters.p->bvh_node_tests;
             ba.tally = tally + (size_t)MODE * (size_t)c->aux_grid * 4;
-            if (c->use_bvh != 2) hipLaunchKernelGGL((k_bvh_trace<MODE, true>), dim3(c->aux_grid), dim3(RT_BVH_BLOCK), 0, st, dsc, ba, A);
-            else hipLaunchKernelGGL((k_bvh_trace<MODE, false>), dim3(c->aux_grid), dim3(RT_BVH_BLOCK), 0, st, dsc, ba, A);
+            if (c->use_bvh != 2) hipLaunchKernelGGL((k_bvh_trace<MODE, true>), dim3(ray_grid), dim3(RT_BVH_BLOCK), 0, st, dsc, ba, A);
+            else hipLaunchKernelGGL((k_bvh_trace<MODE, false>), dim3(ray_grid), dim3(RT_BVH_BLOCK), 0, st, dsc, ba, A);
             // The one hit no box hierarchy finds: a ray that starts exactly in the plane of a triangle and grazes it
             // "hits" it at its own origin wherever the triangle is (raytracer.cpp:319-321).  The bounded scan's own
             // machinery for that question -- camera rays: the triangles the host found the eye's plane distance too
@@ -821,11 +861,11 @@ int launch_trace(rt_ctx* c, const Workspace& W, TraceArgs A, hipStream_t st, siz
     }
     Timed t(c, st, RT_WORK_KINDS, events);
     if (!c->force_exact && c->hs.n_regular > 0 && (!c->use_bvh || guard_scan)) {      // (the LBVH traversal itself lists no pairs)
-        hipLaunchKernelGGL(k_exact_pairs<MODE>, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, dsc,
+        hipLaunchKernelGGL(k_exact_pairs<MODE>, dim3(pair_grid), dim3(RT_BLOCK), 0, st, dsc,
                            (const TriExact*)c->tri_exact.p, A);
         HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_brute<MODE>, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, dsc, (const TriExact*)c->tri_exact.p, A);
+    hipLaunchKernelGGL(k_brute<MODE>, dim3(ray_grid), dim3(RT_BLOCK), 0, st, dsc, (const TriExact*)c->tri_exact.p, A);
     HIP_TRY(hipGetLastError());
     t.stop();
     return 0;
@@ -934,9 +974,15 @@ int run_pass(rt_ctx* c, const Workspace& ws, PassDesc pd, int nrows, hipStream_t
     // workspace has room for them and the scans that read them will run
     const bool scan = keeps_scan_copies(c, ws), scan_shadow = scan && keeps_shadow_copies(c, ws);
     RayQueue q[2] = {queue_of(ws, 0, scan), queue_of(ws, 1, scan)};
-    hipLaunchKernelGGL(k_primary, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, dsc, pd, n_pix, q[0], ws.keys[0],
+    hipLaunchKernelGGL(k_primary, dim3(blocks_for(c, (size_t)n_pix)), dim3(RT_BLOCK), 0, st, dsc, pd, n_pix, q[0], ws.keys[0],
                        ws.pixel_of_ray, c->frame, ws.counts);
     HIP_TRY(hipGetLastError());
+    // Queue lengths of the last pass of this size in this workspace (see PassHint), a quarter on top; none: the pass's pixels
+    const bool hinted = c->grid_hints && ws.hint && ws.hint->n_pix == n_pix && ws.hint->counts[0] == (uint32_t)n_pix && levels + 2 <= 72;
+    auto expected = [&](int k) -> size_t {
+        if (!hinted || ws.hint->counts[k] > (uint32_t)n_pix) return (size_t)n_pix;
+        return std::min<size_t>((size_t)n_pix, (size_t)ws.hint->counts[k] + ws.hint->counts[k] / 4 + 1024);
+    };
     // Per level: nearest hit -> k_hit on the caller's stream; shadow rays -> k_phong on the side
     // stream, beside the next level's nearest-hit launches (both only read what k_hit wrote).
     // The short launches of the deep levels then fill each other's idle SIMDs.  With event
@@ -960,8 +1006,9 @@ int run_pass(rt_ctx* c, const Workspace& ws, PassDesc pd, int nrows, hipStream_t
         ta.rays = q[cur]; ta.n_items = ws.counts + k; ta.keys = ws.keys[cur];
         ta.occl_words = ws.occl_words;
         ta.scan_nearest = (scan && c->all_identity) ? 1 : 0;
-        int rc = launch_trace<0>(c, ws, ta, st, (size_t)n_pix, k == 0, side_work);
+        int rc = launch_trace<0>(c, ws, ta, st, (size_t)n_pix, k == 0, side_work, expected(k));
         if (rc) return rc;
+        const int level_grid = blocks_for(c, expected(k)), hits_grid = blocks_for(c, expected(k + 1));
 
         if (overlap && k >= 2) HIP_TRY(hipStreamWaitEvent(st, ev_phong[k - 2], 0));
         HitArgs ha{};
@@ -970,9 +1017,9 @@ int run_pass(rt_ctx* c, const Workspace& ws, PassDesc pd, int nrows, hipStream_t
         ha.occluded = occl; ha.occl_words = ws.occl_words;
         ha.shadow_scan = scan_shadow ? ws.shadow_scan[cur] : nullptr; ha.shadow_stride = (uint32_t)ws.cap;
         ha.light_frame = c->light_frame.p;
-        hipLaunchKernelGGL(k_hit_offsets, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, (const unsigned long long*)ws.keys[cur],
-                           (const uint32_t*)(ws.counts + k), ws.hit_offsets, ws.counts + k + 1);
-        hipLaunchKernelGGL(k_hit, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, ha);
+        hipLaunchKernelGGL(k_hit_offsets, dim3(level_grid), dim3(RT_BLOCK), 0, st, (const unsigned long long*)ws.keys[cur],
+                           (const uint32_t*)(ws.counts + k), ws.hit_offsets, ws.hit_offsets + c->aux_grid, ws.counts + k + 1);
+        hipLaunchKernelGGL(k_hit, dim3(level_grid), dim3(RT_BLOCK), 0, st, ha);      // (the same grid: a block's range of the queue is the one it counted)
         HIP_TRY(hipGetLastError());
         if (overlap) {
             HIP_TRY(hipEventRecord(ev_hit[k], st));
@@ -984,14 +1031,15 @@ int run_pass(rt_ctx* c, const Workspace& ws, PassDesc pd, int nrows, hipStream_t
             sa.rays = q[nxt]; sa.n_items = ws.counts + k + 1; sa.source_obj = lvl.obj;
             sa.occluded = occl; sa.occl_words = ws.occl_words;
             sa.shadow_scan = scan_shadow ? ws.shadow_scan[cur] : nullptr; sa.shadow_stride = (uint32_t)ws.cap;
-            rc = launch_trace<1>(c, ws, sa, sb, (size_t)n_pix * (size_t)std::max(1, c->hs.n_lights), false, side_work);
+            rc = launch_trace<1>(c, ws, sa, sb, (size_t)n_pix * (size_t)std::max(1, c->hs.n_lights), false, side_work,
+                                 expected(k + 1) * (size_t)std::max(1, c->hs.n_lights));
             if (rc) return rc;
         }
 
         PhongArgs pa{};
         pa.sc = dsc; pa.next = q[nxt]; pa.aux = aux; pa.lvl = lvl; pa.occluded = occl;
         pa.occl_words = ws.occl_words; pa.cap = (uint32_t)ws.cap; pa.n_hits = ws.counts + k + 1;
-        hipLaunchKernelGGL(k_phong, dim3(c->aux_grid), dim3(RT_BLOCK), 0, sb, pa);
+        hipLaunchKernelGGL(k_phong, dim3(hits_grid), dim3(RT_BLOCK), 0, sb, pa);
         HIP_TRY(hipGetLastError());
         if (overlap) HIP_TRY(hipEventRecord(ev_phong[k], sb));
     }
@@ -1002,11 +1050,16 @@ int run_pass(rt_ctx* c, const Workspace& ws, PassDesc pd, int nrows, hipStream_t
         fa.sc = dsc; fa.lvl = level_of(ws, k); fa.parent_lvl = level_of(ws, k > 0 ? k - 1 : 0);
         fa.cap = (uint32_t)ws.cap; fa.n_hits = ws.counts + k + 1; fa.level = k;
         fa.pixel_of_ray = ws.pixel_of_ray; fa.frame = c->frame;
-        hipLaunchKernelGGL(k_fold, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, fa);
+        hipLaunchKernelGGL(k_fold, dim3(blocks_for(c, expected(k + 1))), dim3(RT_BLOCK), 0, st, fa);
         HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(k_count, dim3(1), dim3(64), 0, st, dsc, (const uint32_t*)ws.counts, levels, c->counters.p);
     HIP_TRY(hipGetLastError());
+    // this pass's queue lengths for the next pass of its size (pinned memory: the copy is a device-side write)
+    if (c->grid_hints && ws.hint && levels + 2 <= 72) {
+        ws.hint->n_pix = n_pix;
+        HIP_TRY(hipMemcpyAsync(ws.hint->counts, ws.counts, (size_t)(levels + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    }
     return 0;
 }
 
@@ -2034,6 +2087,8 @@ static int upload_scene(rt_ctx** out, const rt_scene_desc* d) {
 #undef RT_GRID_OF_ALL
 #undef RT_GRID_OF
     c->aux_grid = c->n_cu * 8;
+    if (const char* env = std::getenv("RAYTRACER_AMD_GRID_HINTS")) c->grid_hints = std::atoi(env) ? 1 : 0;
+    if (const char* env = std::getenv("RAYTRACER_AMD_BESIDE_DIV")) c->beside_grid_div = std::max(1, std::min(16, std::atoi(env)));
     // this device's copy of the static workspace (for rt_render_tile_noalloc)
     if (int rc = resolve_scratch(c->device)) return bail(rc);
     *out = c;
@@ -2106,7 +2161,7 @@ int rt_set_option(rt_ctx* c, int option, int64_t value) {
         case RT_OPT_WORK_COUNTERS: c->work_counters = value ? 1 : 0; return 0;
         case RT_OPT_SCAN_COPIES: c->scan_copies = value ? 1 : 0; return 0;
         case RT_OPT_FRAMES_IN_FLIGHT: {
-            if (value < 1 || value > 4) return fail(RT_ERR_ARG, "rt_set_option: 1 to 4 frames in flight");
+            if (value < 1 || value > RT_MAX_FRAMES_IN_FLIGHT) return fail(RT_ERR_ARG, "rt_set_option: 1 to 8 frames in flight");
             HIP_TRY(hipSetDevice(c->device));
             int rc = sync_all(c);
             if (rc) return rc;
@@ -2310,7 +2365,7 @@ int rt_bounce_probe(rt_ctx* c, int y0, int rows, double* point, double* refl, ui
         ha.shadow_scan = scan_shadow ? ws.shadow_scan[0] : nullptr; ha.shadow_stride = (uint32_t)ws.cap;
         ha.light_frame = c->light_frame.p;
         hipLaunchKernelGGL(k_hit_offsets, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, (const unsigned long long*)ws.keys[0],
-                           (const uint32_t*)ws.counts, ws.hit_offsets, ws.counts + 1);
+                           (const uint32_t*)ws.counts, ws.hit_offsets, ws.hit_offsets + c->aux_grid, ws.counts + 1);
         hipLaunchKernelGGL(k_hit, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, ha);
         HIP_TRY(hipGetLastError());
         if (c->hs.n_lights > 0) {
@@ -2433,8 +2488,8 @@ int rt_get_stats(rt_ctx* c, rt_stats* out) {
             }
         }
         out->lanes_share_a_queue = c->lanes.empty() ? 0 : shared;
-        out->caller_stream_shares_a_queue = c->lanes.empty() ? -1
-            : (c->caller_queue < 0 ? -1 : (std::find(seen.begin(), seen.end(), c->caller_queue) != seen.end() ? 1 : 0));
+        out->caller_stream_shares_a_queue = (c->lanes.empty() || !c->caller_probed) ? -1
+            : (c->caller_queue >= 0 && std::find(seen.begin(), seen.end(), c->caller_queue) != seen.end() ? 1 : 0);
     }
     out->n_triangles = c->n_regular_real + c->hs.n_irregular; out->n_spheres = c->hs.n_spheres;
     out->n_groups = c->hs.n_groups; out->n_irregular = c->hs.n_irregular;
@@ -2476,6 +2531,7 @@ void rt_free(rt_ctx* c) {
     c->obj_normals.release(); c->materials.release(); c->lights.release(); c->own_frame.release();
     c->counters.release(); c->work.release();
     c->ws_block.release();
+    if (c->hint) (void)hipHostFree(c->hint);
     drop_lanes(c);
     for (auto st : c->lane_streams) (void)hipStreamDestroy(st);
     for (auto e : c->ev_hit) (void)hipEventDestroy(e);

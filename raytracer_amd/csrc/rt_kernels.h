@@ -2010,8 +2010,9 @@ __device__ __forceinline__ unsigned int hit_range_length(unsigned int n, unsigne
 
 __global__ void __launch_bounds__(RT_BLOCK)
 k_hit_offsets(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ n_rays, uint32_t* offsets,
-              uint32_t* n_hits) {
-    // offsets[0 .. gridDim.x): per block; offsets[gridDim.x]: blocks finished so far (zero between launches)
+              uint32_t* finished, uint32_t* n_hits) {
+    // offsets[0 .. gridDim.x): per block; *finished: blocks finished so far (zero between launches; a place of its
+    // own, whatever the grid: launches of different sizes share the offsets array)
     __shared__ unsigned int part[RT_BLOCK];
     __shared__ bool last_block;
     const unsigned int n = *n_rays, G = gridDim.x;
@@ -2036,7 +2037,7 @@ k_hit_offsets(const unsigned long long* __restrict__ keys, const uint32_t* __res
     if (threadIdx.x == 0) {
         __hip_atomic_store(&offsets[blockIdx.x], part[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence();
-        last_block = atomicAdd(&offsets[G], 1u) == active - 1u;
+        last_block = atomicAdd(finished, 1u) == active - 1u;
     }
     __syncthreads();
     if (!last_block) return;
@@ -2062,7 +2063,7 @@ k_hit_offsets(const unsigned long long* __restrict__ keys, const uint32_t* __res
         offsets[k] = at;
         at += cnt;
     }
-    if (threadIdx.x == RT_BLOCK - 1) { *n_hits = part[RT_BLOCK - 1]; offsets[G] = 0u; }
+    if (threadIdx.x == RT_BLOCK - 1) { *n_hits = part[RT_BLOCK - 1]; *finished = 0u; }
 }
 
 __global__ void __launch_bounds__(RT_BLOCK)

@@ -274,7 +274,7 @@ int main(int argc, char** argv) {
         else { fprintf(stderr, "unexpected argument %s\n", a.c_str()); return 2; }
     }
     if (gpus < 0 || gpus > 64) { fprintf(stderr, "-gpus must be between 1 and 64\n"); return 2; }
-    if (n_frames < 1 || in_flight < 1 || in_flight > 4) { fprintf(stderr, "-frames must be at least 1, -inflight between 1 and 4\n"); return 2; }
+    if (n_frames < 1 || in_flight < 1 || in_flight > 8) { fprintf(stderr, "-frames must be at least 1, -inflight between 1 and 8\n"); return 2; }
     if ((n_frames > 1 || in_flight > 1) && gpus == 0) gpus = 1;       // (the frame loop lives in the N-GPU path)
     // Calls in flight run on a hardware queue each, and the stream the exchange is enqueued on should have one of its
     // own; HIP deals a process 4 unless told otherwise, and reads this at its first call.

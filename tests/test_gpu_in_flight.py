@@ -161,7 +161,7 @@ def test_calls_on_different_rows_land_in_call_order():
     r.render_frame()
     assert np.array_equal(r.download(), want)
     with pytest.raises(Exception):
-        r.set_option(abi.RT_OPT_FRAMES_IN_FLIGHT, 5)
+        r.set_option(abi.RT_OPT_FRAMES_IN_FLIGHT, 9)
     r.close()
 
 
@@ -229,3 +229,31 @@ def test_the_deal_of_the_lanes_is_in_the_statistics():
             assert st["lanes_share_a_queue"] == 0
         assert st["caller_stream_shares_a_queue"] in (0, 1)
     r.close()
+
+
+def test_launch_geometry_hints_change_nothing(monkeypatch):
+    """The streaming kernels of a pass are launched with grids sized for the queue lengths of the last pass of the
+    same size (PassHint); frames and counters must be the same with the hints on and off, also when a hint is stale
+    (a pass of the same size over other rows, whose queues have other lengths)."""
+    from raytracer_amd.render import Renderer
+    sc = Scene.load(os.path.join(ROOT, "scenes", "teapot.scene"), 320, 180, 5)
+    results = {}
+    for hints in ("0", "1"):
+        monkeypatch.setenv("RAYTRACER_AMD_GRID_HINTS", hints)
+        r = Renderer(sc)
+        frames = []
+        for _ in range(3):                       # (the second and third frame are traced with the first one's lengths)
+            r.render_frame()
+            frames.append(r.download())
+        # the same number of rows elsewhere in the frame: the hint of the previous pass does not fit this one
+        r.render_tile(0, 60)
+        r.render_tile(120, 60)
+        r.render_tile(60, 60)
+        frames.append(r.download())
+        results[hints] = (frames, r.stats())
+        r.close()
+    for a, b in zip(results["0"][0], results["1"][0]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(results["1"][0][0], results["1"][0][2]) and np.array_equal(results["1"][0][0], results["1"][0][3])
+    for k in COUNTS + ("exact_tests", "flagged_rays"):
+        assert results["0"][1][k] == results["1"][1][k], k

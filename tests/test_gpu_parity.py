@@ -456,7 +456,7 @@ def test_cli_driver_frames_in_flight(tmp_path):
         for k in ("rays_primary", "rays_reflect", "rays_shadow", "hits"):
             assert st[k] == frames * rays1[k], (k, frames, in_flight)
         assert np.array_equal(oracle_api.load_png(str(out)), oracle_api.load_png(str(one))), (frames, in_flight)
-    res = subprocess.run([exe, scene, str(one), "-inflight", "5"] + common, capture_output=True, text=True)
+    res = subprocess.run([exe, scene, str(one), "-inflight", "9"] + common, capture_output=True, text=True)
     assert res.returncode == 2
 
 
@@ -491,3 +491,34 @@ def test_cli_driver_packed_exchange_option(tmp_path):
     assert subprocess.run([exe, scene, str(a), "-gpus", "1"] + common, capture_output=True, text=True).returncode == 0
     assert subprocess.run([exe, scene, str(b), "-gpus", "1", "-packed"] + common, capture_output=True, text=True).returncode == 0
     assert np.array_equal(oracle_api.load_png(str(a)), oracle_api.load_png(str(b)))
+
+
+def test_slot_order_changes_nothing(tmp_path, monkeypatch):
+    """The order of the triangles inside a (transform, axis) run is free: file order (kept for meshes written patch by
+    patch), or the order along a space-filling curve through the centroids (taken for meshes whose faces come in no
+    spatial order).  A teapot with its faces shuffled must give the same frame and counts in either order as in the
+    reference-precision scan of everything, and must be given the curve order by the upload's own choice."""
+    import random
+    src = open(os.path.join(ROOT, "scenes", "teapot.obj")).read().splitlines()
+    faces = [ln for ln in src if ln.startswith("f ")]
+    rest = [ln for ln in src if not ln.startswith("f ")]
+    random.Random(7).shuffle(faces)
+    (tmp_path / "teapot.obj").write_text("\n".join(rest + faces) + "\n")
+    scene_text = open(os.path.join(ROOT, "scenes", "teapot.scene")).read()
+    (tmp_path / "shuffled.scene").write_text(scene_text)
+    monkeypatch.chdir(tmp_path)                      # (obj paths are relative to the working directory, raytracer.cpp:802-805)
+    sc = Scene.load(str(tmp_path / "shuffled.scene"), 192, 108, 3)
+    want, st_want = gpu_render(sc, exact_only=True)
+    got = {}
+    for order in ("file", "curve", ""):
+        if order:
+            monkeypatch.setenv("RAYTRACER_AMD_SLOT_ORDER", order)
+        else:
+            monkeypatch.delenv("RAYTRACER_AMD_SLOT_ORDER")
+        img, st = gpu_render(sc)
+        assert np.array_equal(img, want), order
+        for key in ("rays_reflect", "rays_shadow", "hits"):
+            assert st[key] == st_want[key], (order, key)
+        got[order] = st["exact_tests"]
+    # the upload's own choice for a shuffled mesh is the curve (compact clusters list the pairs the curve order lists)
+    assert got[""] == got["curve"]

@@ -9,7 +9,7 @@ sc = Scene.load('scenes/teapot.scene', 3840, 2160, 5)
 worlds = [int(a) for a in sys.argv[1:]] or [1, 8]
 r = Renderer(sc)
 stream = torch.cuda.current_stream().cuda_stream
-frames = [torch.zeros((2160, 3840, 4), dtype=torch.uint8, device='cuda') for _ in range(4)]
+frames = [torch.zeros((2160, 3840, 4), dtype=torch.uint8, device='cuda') for _ in range(8)]
 calls = [0]
 
 
@@ -32,8 +32,8 @@ def timed(fn, steps=12):
 for own_frames in (1,):
   r.bind_frame(frames[0])
   print('a frame buffer per call in flight' if own_frames else 'one frame buffer (folds in call order)')
-  for order in ((1, 2, 3, 4),):
-    for bvh in (0, 1):
+  for order in ((4, 8),):
+    for bvh in (0,):
         r.set_option(abi.RT_OPT_USE_BVH, bvh)
         for world in worlds:
             res = []

@@ -7,7 +7,7 @@ OUT=gpurun_out/pmc_${TAG:-r2}      # (remove the local copy of this directory be
 rm -rf $OUT
 mkdir -p $OUT
 # two brute-force frames per pass: the timed one and the one of the kernel-timing leg
-CMD="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-lbvh --no-config5"
+CMD="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-lbvh --no-config4 --no-config5"
 run() { name=$1; shift; timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- $CMD > $OUT/$name.log 2>&1 || { echo "pass $name failed"; tail -3 $OUT/$name.log; exit 1; }; echo "pass $name done"; }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY && \
 run sq2 SQ_INSTS_SMEM SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT && \
