@@ -41,7 +41,20 @@ def test_struct_sizes_match_c():
     assert C.sizeof(abi.RtTransform) == 48 * 8
     assert C.sizeof(abi.RtLight) == 6 * 8 + 8
     assert C.sizeof(abi.RtSceneDesc) == 24 + 18 * 8 + 16 + 9 * 8
-    assert C.sizeof(abi.RtStats) == 11 * 8 + 3 * 8 + 3 * 4 + 5 * 4 + 8 + 2 * 4 + 6 * 11 * 8 + 6 * 8 + 6 * 4
+    assert C.sizeof(abi.RtStats) == 11 * 8 + 3 * 8 + 3 * 4 + 5 * 4 + 8 + 2 * 4 + 6 * 11 * 8 + 6 * 8 + 6 * 4 + 4 * 4
+
+
+def test_struct_sizes_match_the_compiler(tmp_path):
+    """... and what the C compiler makes of include/rt_abi.h itself."""
+    import subprocess
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "rt_abi.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(rt_material), '
+                   'sizeof(rt_transform), sizeof(rt_light), sizeof(rt_scene_desc), sizeof(rt_stats), sizeof(rt_scan_work)); return 0; }\n')
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    want = [C.sizeof(t) for t in (abi.RtMaterial, abi.RtTransform, abi.RtLight, abi.RtSceneDesc, abi.RtStats, abi.RtScanWork)]
+    assert got == want
 
 
 def test_upload_without_gpu_fails_loudly():
