@@ -1,0 +1,172 @@
+// The reference-precision kernels of a trace launch: the listed pairs (k_exact_pairs) and everything the filter
+// does not cover (k_brute).
+#pragma once
+
+#include "rt_trace_args.h"
+
+// One thread per listed (ray, triangle) pair.
+template <int MODE>
+__global__ void __launch_bounds__(RT_BLOCK)
+k_exact_pairs(const DevScene* __restrict__ sc, const TriExact* __restrict__ exact, TraceArgs A) {
+    // the sub-lists one after the other: first[l] = entries in the sub-lists before l
+    __shared__ unsigned int first[RT_PAIR_LISTS + 1];
+    if (threadIdx.x < RT_PAIR_LISTS) {
+        unsigned long long listed = 0;
+        if (threadIdx.x < A.pair_lists) listed = A.pair_count[16 * threadIdx.x];
+        first[threadIdx.x + 1] = listed < A.pair_seg ? (unsigned int)listed : A.pair_seg;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int sum = 0;
+        first[0] = 0;
+        for (int l = 1; l <= RT_PAIR_LISTS; l++) { sum += first[l]; first[l] = sum; }
+    }
+    __syncthreads();
+    const unsigned int n = first[RT_PAIR_LISTS];
+    const unsigned int n_lights = sc->n_lights;
+    const unsigned int n_hits = *A.n_items;
+    const unsigned int n_rays = (MODE == 0) ? n_hits : n_hits * n_lights;
+    const unsigned int n_regular = (unsigned int)sc->n_regular;
+    const float eps = (MODE == 0) ? sc->eps : sc->shadow_eps;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        unsigned int l = 0;
+#pragma unroll
+        for (unsigned int step = RT_PAIR_LISTS / 2; step > 0; step >>= 1)
+            if (first[l + step] <= i) l += step;
+        const unsigned long long pr = A.pairs[(size_t)l * A.pair_seg + (i - first[l])];
+        const unsigned int ray = (unsigned int)(pr >> 32), slot = (unsigned int)pr;
+        // Every entry below n was written by this launch's producers; the check only keeps a
+        // producer bug from turning into an out-of-range access.
+        if (ray >= n_rays || slot >= n_regular) continue;
+        const TriExact& T = exact[slot];
+        // (no scan lists a hole; asked only at the end, so that this load does not stand in front of the others)
+        const bool is_hole = T.hole != 0;
+        int ident = 1;
+        const double* X = sc->xforms;
+        if (MODE == 0) {
+            const Group& G = sc->groups[T.grp];
+            ident = G.identity;
+            X = sc->xforms + 48 * (size_t)G.xf;
+        }
+        d3 pos, vec;
+        int source;
+        load_world_ray<MODE>(A, sc, ray, n_hits, &pos, &vec, &source);
+        to_object_space(X, ident, &pos, &vec);
+        bool q7 = false;
+        const float t = tri_intersect_exact(T, pos, vec, eps, &q7);
+        if (is_hole) continue;
+        if (q7) atomicAdd(&A.counters->in_plane_origin_hits, 1ull);
+        publish_result<MODE>(A, ray, n_hits, t, T.obj, pos, vec, X, ident, source);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&A.counters->exact_tests, (unsigned long long)n);
+}
+
+// One ray per lane, every primitive the filter does not cover, in reference arithmetic.
+template <int MODE>
+__global__ void __launch_bounds__(RT_BLOCK)
+k_brute(const DevScene* __restrict__ sc, const TriExact* __restrict__ exact, TraceArgs A) {
+    const int lane = threadIdx.x & (RT_WAVE - 1);
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / RT_WAVE);
+    const unsigned int n_waves = gridDim.x * (RT_BLOCK / RT_WAVE);
+    const unsigned int wave_id = blockIdx.x * (RT_BLOCK / RT_WAVE) + wave_in_block;
+    const unsigned int n_lights = sc->n_lights;
+    const unsigned int n_hits = __builtin_amdgcn_readfirstlane(*A.n_items);
+    const unsigned int n_rays = (MODE == 0) ? n_hits : n_hits * n_lights;
+    const unsigned int n_ray_blocks = (n_rays + RT_WAVE - 1) / RT_WAVE;
+    if (n_ray_blocks == 0) return;
+    const int NR = sc->n_regular, NI = sc->n_irregular, NS = sc->n_spheres;
+    // nothing but flagged rays could need this kernel, and no ray is flagged: done (one scalar load)
+    if (NS + NI == 0 && !A.scan_all && __builtin_amdgcn_readfirstlane(*(const volatile unsigned int*)A.any_flagged) == 0u) return;
+    int max_split = (NR + 255) / 256;
+    if (max_split < 1) max_split = 1;
+    int split = 1;
+    if (n_ray_blocks < 2u * n_waves) {
+        split = (int)((2u * n_waves + n_ray_blocks - 1) / n_ray_blocks);
+        if (split > max_split) split = max_split;
+    }
+    const unsigned int n_tasks = n_ray_blocks * (unsigned int)split;
+    const float eps = (MODE == 0) ? sc->eps : sc->shadow_eps;
+    const int n_groups = (MODE == 0) ? sc->n_groups : 1;
+    unsigned int n_exact = 0;
+
+    for (unsigned int task = wave_id; task < n_tasks; task += n_waves) {
+        const int part = __builtin_amdgcn_readfirstlane((int)(task / n_ray_blocks));
+        const unsigned int rb = task - (unsigned int)part * n_ray_blocks;
+        const unsigned int ray = rb * RT_WAVE + lane;
+        const bool valid = ray < n_rays;
+        const bool scan = valid && (A.scan_all || A.ray_flags[ray] != 0);
+        const bool any_scan = __any(scan);
+        if (part == 0 && !A.scan_all && any_scan) {
+            const unsigned long long m = __ballot(scan);
+            if (lane == 0) atomicAdd(&A.counters->flagged_rays, (unsigned long long)__popcll(m));
+        }
+        if (!any_scan && (part != 0 || NS + NI == 0)) continue;
+        d3 wpos = mk3(0, 0, 0), wvec = mk3(0, 0, 1);
+        int source = -1;
+        if (valid) load_world_ray<MODE>(A, sc, ray, n_hits, &wpos, &wvec, &source);
+
+        if (part == 0 && valid) {
+            // an FP32 pre-test decides most (ray, sphere) pairs; the rest take the reference's arithmetic
+            const float fpx = (float)wpos.x, fpy = (float)wpos.y, fpz = (float)wpos.z;
+            const float fvx = (float)wvec.x, fvy = (float)wvec.y, fvz = (float)wvec.z;
+            const float p1 = fabsf(fpx) + fabsf(fpy) + fabsf(fpz), v1 = fabsf(fvx) + fabsf(fvy) + fabsf(fvz);
+            for (int s = 0; s < NS; s++) {
+                const SphereFilt& F = sc->sphere_filt[s];
+                if (!A.scan_all && !sphere_may_hit(F, MODE == 0 && !F.identity, fpx, fpy, fpz, fvx, fvy, fvz, p1, v1, eps)) continue;
+                const SphereRec& S = sc->spheres[s];
+                const double* X = sc->xforms + 48 * (size_t)S.xf;
+                d3 pos = wpos, vec = wvec;
+                const int ident = (MODE == 0) ? S.identity : 1;   // shadow rays are never transformed (raytracer.cpp:553)
+                to_object_space(X, ident, &pos, &vec);
+                const float t = sph_intersect_exact(S, pos, vec, eps);
+                publish_result<MODE>(A, ray, n_hits, t, S.obj, pos, vec, X, ident, source);
+                n_exact++;
+            }
+        }
+        for (int g = 0; g < n_groups; g++) {
+            int fbeg = 0, fend = NR, ibeg = NR, iend = NR + NI, ident = 1;
+            const double* X = sc->xforms;
+            if (MODE == 0) {
+                const Group& G = sc->groups[g];
+                fbeg = __builtin_amdgcn_readfirstlane(G.fax[0]); fend = __builtin_amdgcn_readfirstlane(G.fax[3]);
+                ibeg = __builtin_amdgcn_readfirstlane(G.ibeg); iend = __builtin_amdgcn_readfirstlane(G.iend);
+                ident = __builtin_amdgcn_readfirstlane(G.identity);
+                X = sc->xforms + 48 * (size_t)__builtin_amdgcn_readfirstlane(G.xf);
+            }
+            d3 pos = wpos, vec = wvec;
+            to_object_space(X, ident, &pos, &vec);
+            if (part == 0 && valid) {
+                for (int i = ibeg; i < iend; i++) {
+                    const float t = tri_intersect_exact(exact[i], pos, vec, eps);
+                    publish_result<MODE>(A, ray, n_hits, t, exact[i].obj, pos, vec, X, ident, source);
+                    n_exact++;
+                }
+            }
+            if (any_scan) {
+                const int glen = fend - fbeg;
+                const int per_part = __builtin_amdgcn_readfirstlane((glen + split - 1) / split);
+                const int pbeg = fbeg + part * per_part;
+                const int pend = min(fend, pbeg + per_part);
+                // The whole wave works on one flagged ray at a time, 64 triangles per step: a
+                // handful of flagged rays must not turn into a long single-lane tail.
+                unsigned long long todo = __ballot(scan);
+                while (todo) {
+                    const int src = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    const d3 bpos = mk3(__shfl(pos.x, src), __shfl(pos.y, src), __shfl(pos.z, src));
+                    const d3 bvec = mk3(__shfl(vec.x, src), __shfl(vec.y, src), __shfl(vec.z, src));
+                    const unsigned int bray = (unsigned int)__shfl((int)ray, src);
+                    const int bsource = __shfl(source, src);
+                    for (int j = pbeg + lane; j < pend; j += RT_WAVE) {
+                        if (exact[j].hole) continue;
+                        const float t = tri_intersect_exact(exact[j], bpos, bvec, eps);
+                        publish_result<MODE>(A, bray, n_hits, t, exact[j].obj, bpos, bvec, X, ident, bsource);
+                        n_exact++;
+                    }
+                }
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) n_exact += __shfl_xor(n_exact, off);
+    if (lane == 0 && n_exact) atomicAdd(&A.counters->exact_tests, (unsigned long long)n_exact);
+}
