@@ -44,8 +44,14 @@ import time
 # itself enqueues on (joins, the exchange) should not sit on one of them: what it is given would queue up behind a
 # whole frame of that lane.  HIP deals a process 4 queues unless told otherwise, and reads this when it starts up --
 # before torch is imported.  (4 queues: 4.7-5.1 ms per frame depending on which lane the caller's stream shares a
-# queue with; 8: 4.6-5.0; 16: 4.61-4.63.)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# queue with; 8: 4.6-5.0; 16: 4.56-4.63.)  The line this program prints records what the library found
+# (config.frames_in_flight_queues).
+try:
+    _queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "0"))
+except ValueError:
+    _queues = 0
+if _queues < 16:            # (also when the environment exports HIP's default of 4, as the GPU boxes of this pool do)
+    os.environ["GPU_MAX_HW_QUEUES"] = "16"
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

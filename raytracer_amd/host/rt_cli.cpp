@@ -278,7 +278,11 @@ int main(int argc, char** argv) {
     if ((n_frames > 1 || in_flight > 1) && gpus == 0) gpus = 1;       // (the frame loop lives in the N-GPU path)
     // Calls in flight run on a hardware queue each, and the stream the exchange is enqueued on should have one of its
     // own; HIP deals a process 4 unless told otherwise, and reads this at its first call.
-    if (in_flight > 1) setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    // (an environment that exports a smaller number -- HIP's default of 4, say -- is raised as well)
+    if (in_flight > 1) {
+        const char* have = std::getenv("GPU_MAX_HW_QUEUES");
+        if (!have || std::atoi(have) < 16) setenv("GPU_MAX_HW_QUEUES", "16", 1);
+    }
     printf("Ray Tracer!\n");
     auto now = []() { return std::chrono::steady_clock::now(); };
     auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(now() - t).count(); };
