@@ -10,6 +10,7 @@
 #define RT_MISS_T 3.402823466e+38f          // MAXFLOAT: the reference's miss sentinel
 #define RT_MISS_KEY 0x7f7fffffffffffffull   // (bits(MAXFLOAT) << 32) | 0xffffffff
 
+#define RT_GRP_IDENTITY 0x40000000
 struct d3 { double x, y, z; };
 
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -25,7 +26,8 @@ struct __attribute__((aligned(16))) TriExact {
     double n[3];       // (edge2 ^ edge1).normalize() (raytracer.cpp:313)
     float uu, uv, vv, D;   // raytracer.cpp:334-340, each rounded as the reference does
     int32_t obj;       // index in Scene::objects
-    int32_t grp;       // index of the transform group
+    int32_t grp;       // index of the transform group; RT_GRP_IDENTITY set: the group's transform is the identity
+                       // (whoever only needs to know that is spared the load of the group's record)
     float box_pad;     // how far outside the triangle the reference's own rounding can accept a point
     int32_t hole;      // 1: no triangle here (a slot between the end of an axis range and the next multiple of 64)
 };

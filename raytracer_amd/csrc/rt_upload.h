@@ -210,8 +210,9 @@ int install_filter(rt_ctx* c, int robust) {
             G.ibeg = NR + q;
             while (q < NI && tris[order_irr[q]].xf == x) q++;
             G.iend = NR + q;
-            for (int k2 = G.fax[0]; k2 < G.fax[3]; k2++) exact[k2].grp = (int32_t)groups.size();
-            for (int k2 = G.ibeg; k2 < G.iend; k2++) exact[k2].grp = (int32_t)groups.size();
+            const int32_t grp_word = (int32_t)groups.size() | (G.identity ? RT_GRP_IDENTITY : 0);
+            for (int k2 = G.fax[0]; k2 < G.fax[3]; k2++) exact[k2].grp = grp_word;
+            for (int k2 = G.ibeg; k2 < G.iend; k2++) exact[k2].grp = grp_word;
             groups.push_back(G);
         }
     }
