@@ -39,12 +39,14 @@ struct Workspace {
     double *lvl_phong = nullptr, *lvl_child = nullptr; // [levels][3][cap]
     uint32_t* counts = nullptr;                        // [levels + 2]
     uint32_t* hit_offsets = nullptr;                   // [aux_grid + 1]: k_hit_offsets -> k_hit
-    // [RT_FLAGS_HEADER + rays]: the pair list's fill counters and the task counter in front of the per-ray
-    // flags, so that one fill clears them all before a launch; one set per kind of query
-    // ([0] nearest hit, [1] shadow) so that a level's shadow launches can run beside the next
-    // level's nearest-hit launches
+    // Three launch headers (the pair list's fill counters, the task counter, ...) and two arrays of per-ray flags, which
+    // the trace launches take in turn (RT_FLAGS_HEADER); one set per kind of query ([0] nearest hit, [1] shadow) so
+    // that a level's shadow launches can run beside the next level's nearest-hit launches
     uint8_t* ray_flags[2] = {nullptr, nullptr};
-    size_t ray_flags_n[2] = {0, 0};
+    size_t ray_flags_n[2] = {0, 0};                    // bytes of the whole set
+    size_t flags_stride[2] = {0, 0};                   // bytes from one flag array to the other
+    mutable unsigned int launch_no[2] = {0, 0};        // trace launches of the kind enqueued so far
+    mutable bool flags_clean[2] = {false, false};      // ... and the last one was enqueued to its end (else: one fill of the set)
     unsigned long long* pairs[2] = {nullptr, nullptr};
     size_t pair_cap[2] = {0, 0};
     // FP32 scan copies (RayQueue::scan, TraceArgs::shadow_scan); null when the workspace keeps none

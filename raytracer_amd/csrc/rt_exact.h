@@ -79,8 +79,7 @@ k_exact_pairs(const DevScene* __restrict__ sc, const TriExact* __restrict__ exac
 
 // One ray per lane, every primitive the filter does not cover, in reference arithmetic.
 template <int MODE>
-__global__ void __launch_bounds__(RT_BLOCK)
-k_brute(const DevScene* __restrict__ sc, const TriExact* __restrict__ exact, TraceArgs A) {
+__device__ __forceinline__ void brute_scan(const DevScene* __restrict__ sc, const TriExact* __restrict__ exact, const TraceArgs& A) {
     const int lane = threadIdx.x & (RT_WAVE - 1);
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / RT_WAVE);
     const unsigned int n_waves = gridDim.x * (RT_BLOCK / RT_WAVE);
@@ -185,4 +184,27 @@ k_brute(const DevScene* __restrict__ sc, const TriExact* __restrict__ exact, Tra
     }
     for (int off = 32; off > 0; off >>= 1) n_exact += __shfl_xor(n_exact, off);
     if (lane == 0 && n_exact) atomicAdd(&A.counters->exact_tests, (unsigned long long)n_exact);
+}
+
+// The last kernel of a trace launch: brute_scan, and the housekeeping that spares every launch a fill in front of it.
+// Launches of one kind follow each other on a stream and take three headers and two flag arrays in turn; this launch
+// clears the flags of the launch before it, if that one set any (all blocks, a slice each), and the header of the launch
+// after it (block 0) -- memory that no kernel of this launch or of a launch still running touches otherwise.
+template <int MODE>
+__global__ void __launch_bounds__(RT_BLOCK)
+k_brute(const DevScene* __restrict__ sc, const TriExact* __restrict__ exact, TraceArgs A) {
+    brute_scan<MODE>(sc, exact, A);
+    if (__builtin_amdgcn_readfirstlane(A.prev_words[1]) != 0u) {
+        const size_t n_prev = A.prev_words[2];
+        uint4* wide = (uint4*)A.prev_ray_flags;                     // (a flag array starts at a multiple of 256 bytes and ends at one)
+        for (size_t k = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x; k < (n_prev + 15) / 16; k += (size_t)gridDim.x * RT_BLOCK)
+            wide[k] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (blockIdx.x == 0) {
+        for (unsigned int k = threadIdx.x; k < RT_FLAGS_HEADER / 8; k += RT_BLOCK) A.next_header[k] = 0ull;
+        if (threadIdx.x == 0) {
+            const unsigned int n_hits = *A.n_items;
+            A.task_counter[2] = (MODE == 0) ? n_hits : n_hits * (unsigned int)sc->n_lights;
+        }
+    }
 }

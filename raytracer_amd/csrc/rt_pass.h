@@ -55,12 +55,19 @@ int launch_trace(rt_ctx* c, const Workspace& W, TraceArgs A, hipStream_t st, siz
     A.graze_slots = c->graze_slots.p; A.graze_start = c->graze_start.p;
     if (MODE == 1 && light_bounds) A.plane_any = c->plane_any.p;
     A.cl_sphere = c->cl_sphere.p; A.cl_normal = c->cl_normal.p; A.n_clusters = c->n_clusters;
-    // (the header in front of the flags: RT_PAIR_LISTS fill counters on a 128-byte line each, then 16 bytes with
-    // the task counter and "some ray is flagged")
-    A.pair_count = (unsigned long long*)W.ray_flags[MODE];
-    A.task_counter = (unsigned int*)(W.ray_flags[MODE] + RT_FLAGS_HEADER - 8);
+    // this launch's header and flags, the launch before's, the next one's (see RT_FLAGS_HEADER)
+    const unsigned int x = W.launch_no[MODE]++;
+    uint8_t* const set = W.ray_flags[MODE];
+    uint8_t* const flags = set + 3 * (size_t)RT_FLAGS_HEADER;
+    auto header = [&](unsigned int k) { return set + (size_t)(k % 3u) * RT_FLAGS_HEADER; };
+    A.pair_count = (unsigned long long*)header(x);
+    A.task_counter = (unsigned int*)(header(x) + RT_PAIR_LISTS * 128);
     A.any_flagged = A.task_counter + 1;
-    A.ray_flags = W.ray_flags[MODE] + RT_FLAGS_HEADER; A.pairs = W.pairs[MODE];
+    A.prev_words = (const unsigned int*)(header(x + 2u) + RT_PAIR_LISTS * 128);
+    A.next_header = (unsigned long long*)header(x + 1u);
+    A.ray_flags = flags + (size_t)(x & 1u) * W.flags_stride[MODE];
+    A.prev_ray_flags = flags + (size_t)((x + 1u) & 1u) * W.flags_stride[MODE];
+    A.pairs = W.pairs[MODE];
     A.pair_cap = (unsigned int)W.pair_cap[MODE]; A.counters = c->counters.p; A.scan_all = c->force_exact;
     // as many sub-lists as leave each at least 65536 entries (a flush appends up to 4096)
     A.pair_lists = 1;
@@ -68,9 +75,13 @@ int launch_trace(rt_ctx* c, const Workspace& W, TraceArgs A, hipStream_t st, siz
     A.pair_seg = (unsigned int)(W.pair_cap[MODE] / A.pair_lists);
     const bool work = c->work_counters && c->work.p;
     A.work = work ? c->work.p : nullptr;
-    // (no queue of the pass is longer than max_rays; beyond the expected length a flag may be left over from an earlier
-    // launch: such a ray takes the full reference-precision scan, which costs time, not pixels)
-    HIP_TRY(hipMemsetAsync(W.ray_flags[MODE], 0, std::min(W.ray_flags_n[MODE], std::min(max_rays, est_rays + est_rays / 4 + 4096) + RT_FLAGS_HEADER), st));
+    // Headers and flags are at zero when a launch starts: the launches keep them so among themselves; only a workspace
+    // that is new, or whose last launch of this kind was not enqueued to its end, is cleared here.
+    // (RAYTRACER_AMD_CLEAR_EVERY_LAUNCH=1, a diagnostic switch: the fill in front of every launch all the same)
+    const char* const clear_env = std::getenv("RAYTRACER_AMD_CLEAR_EVERY_LAUNCH");
+    const bool clear_always = clear_env && std::atoi(clear_env) != 0;
+    if (!W.flags_clean[MODE] || clear_always) HIP_TRY(hipMemsetAsync(W.ray_flags[MODE], 0, W.ray_flags_n[MODE], st));
+    W.flags_clean[MODE] = false;
     bool guard_scan = false;              // LBVH mode: the in-plane-origin scan ran and listed pairs
     if (!c->force_exact && c->hs.n_regular > 0) {
         int scan_kind = MODE == 0 ? 0 : 5;
@@ -151,6 +162,7 @@ int launch_trace(rt_ctx* c, const Workspace& W, TraceArgs A, hipStream_t st, siz
     }
     hipLaunchKernelGGL(k_brute<MODE>, dim3(ray_grid), dim3(RT_BLOCK), 0, st, dsc, (const TriExact*)c->tri_exact.p, A);
     HIP_TRY(hipGetLastError());
+    W.flags_clean[MODE] = true;
     t.stop();
     return 0;
 }

@@ -24,6 +24,12 @@
 #endif
 // a staged candidate (u16) = triangle index relative to a chunk base | ray slot << shift
 #define RT_PAIR_LISTS 64        // sub-lists of the pair list at most (see TraceArgs::pair_count)
+// A trace launch's counters (the header: RT_PAIR_LISTS fill counters of the pair list on a 128-byte line each, then a
+// line with the task counter, "some ray is flagged" and the launch's number of rays) and its per-ray flags.  A workspace
+// keeps three headers and two flag arrays per kind of query and launches take them in turn, so that every launch finds
+// its own at zero without a fill in front of it: launch x clears header x + 1 and, if launch x - 1 flagged rays, that
+// launch's flags (see k_brute).
+#define RT_FLAGS_HEADER (RT_PAIR_LISTS * 128 + 128)
 #define RT_SLOT_SHIFT(RPL) ((RPL) <= 2 ? 15 : ((RPL) <= 4 ? 14 : 13))
 
 struct RayQueue {               // structure of arrays, one entry per ray

@@ -40,6 +40,12 @@ struct TraceArgs {
     unsigned int* task_counter;          // k_filter: next task to hand out (zeroed before the launch)
     unsigned int* any_flagged;           // set to 1 by whoever sets a ray flag (zeroed before the launch): lets k_brute
                                          // leave at once when no ray is flagged and the scene has nothing else for it
+    // k_brute, the last kernel of a launch, prepares the launches behind it: prev_words = {task counter, "some ray was
+    // flagged", number of rays} of the launch before this one, whose flags (prev_ray_flags) are cleared if it set any;
+    // next_header: the header the next launch will use, cleared.  task_counter[2] receives this launch's number of rays.
+    const unsigned int* prev_words;
+    uint8_t* prev_ray_flags;
+    unsigned long long* next_header;
     unsigned int pair_cap;
     DevCounters* counters;
     // Per regular-triangle constants that let k_filter skip work shared by all rays of a launch:

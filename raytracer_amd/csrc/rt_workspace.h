@@ -30,7 +30,6 @@ LevelStore level_of(const Workspace& w, int k) {
 // `pairs_per_ray` entries per ray of the largest launch of their kind (a few are typical; a
 // list that runs full sends its rays through the full reference-precision scan instead), at
 // least `min_pairs`, at most 2^28.
-#define RT_FLAGS_HEADER (RT_PAIR_LISTS * 128 + 16)     // bytes in front of a workspace's ray flags (see launch_trace)
 // `scan_copies`: also room for the FP32 scan copies of the rays (shadow rays: up to RT_SCAN_MAX_LIGHTS lights).
 #define RT_SCAN_MAX_LIGHTS 8
 size_t carve_workspace(Workspace* w, unsigned char* base, size_t cap, int levels, int n_lights, int aux_grid,
@@ -59,9 +58,12 @@ size_t carve_workspace(Workspace* w, unsigned char* base, size_t cap, int levels
     t.hit_offsets = (uint32_t*)take(((size_t)aux_grid + 1) * sizeof(uint32_t));
     const size_t max_rays[2] = {cap, cap * (size_t)std::max(1, n_lights)};
     for (int m = 0; m < 2; m++) {
-        t.ray_flags_n[m] = max_rays[m] + RT_FLAGS_HEADER;
+        t.flags_stride[m] = (max_rays[m] + 255) & ~(size_t)255;
+        t.ray_flags_n[m] = 3 * (size_t)RT_FLAGS_HEADER + 2 * t.flags_stride[m];
         t.ray_flags[m] = (uint8_t*)take(t.ray_flags_n[m]);
         t.pair_cap[m] = std::min<size_t>(std::max<size_t>(max_rays[m] * pairs_per_ray, min_pairs), (size_t)1 << 28);
+        // (test hook: a pair list of at most so many entries -- 0: every ray with a candidate takes the full scan)
+        if (const char* env = std::getenv("RAYTRACER_AMD_PAIR_CAP")) t.pair_cap[m] = std::min<size_t>(t.pair_cap[m], (size_t)std::strtoull(env, nullptr, 10));
         t.pairs[m] = (unsigned long long*)take(t.pair_cap[m] * sizeof(unsigned long long));
     }
     if (scan_copies) {

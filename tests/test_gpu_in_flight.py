@@ -257,3 +257,59 @@ def test_launch_geometry_hints_change_nothing(monkeypatch):
     assert np.array_equal(results["1"][0][0], results["1"][0][2]) and np.array_equal(results["1"][0][0], results["1"][0][3])
     for k in COUNTS + ("exact_tests", "flagged_rays"):
         assert results["0"][1][k] == results["1"][1][k], k
+
+
+def test_launches_leave_their_counters_and_flags_clean(monkeypatch, tmp_path):
+    """No fill runs in front of a trace launch: the launches of a kind take three headers and two flag arrays in turn and
+    the last kernel of each clears what the ones behind it will use.  With a pair list of no entries every ray that has a
+    candidate is flagged for the full reference-precision scan -- a deterministic set -- so a flag that is left over
+    from an earlier launch, or cleared while it is needed, shows in `flagged_rays`, and a lost one in the frame.  Held
+    against the same frames with the fill forced in front of every launch, one call at a time and four in flight."""
+    import torch
+    from raytracer_amd.render import Renderer
+    sc = Scene.load(os.path.join(ROOT, "scenes", "teapot.scene"), 160, 90, 3)
+    ref = Renderer(sc)
+    ref.render_frame()
+    want = ref.download()
+    ref.close()
+    monkeypatch.setenv("RAYTRACER_AMD_PAIR_CAP", "0")
+    lone = tmp_path / "lone.scene"
+    lone.write_text("cam 0 0 2  -1 -1 1  1 -1 1  -1 1 1  1 1 1\nmat 0.1 0.1 0.1  0.6 0.5 0.4  0.3 0.3 0.3  16  0 0 0\n"
+                    "tri -0.3 -0.25 -3  0.3 -0.25 -3  0 0.25 -3\nlta 0.2 0.2 0.2\nltp 2 2 2  1 1 1\n")
+    seen = {}
+    for clear in ("1", "0"):
+        monkeypatch.setenv("RAYTRACER_AMD_CLEAR_EVERY_LAUNCH", clear)
+        r = Renderer(sc)
+        counts = []
+        for k in range(4):
+            r.reset_stats()
+            r.render_frame()
+            assert np.array_equal(r.download(), want), (clear, k)
+            counts.append(r.stats()["flagged_rays"])
+        assert counts[0] > 0 and len(set(counts)) == 1, (clear, counts)
+        # Depth 0: one launch of each kind per pass, so the pass after the next meets the flag array of this one.  Bands
+        # that cut the scene's only triangle differently, with empty bands in between: a band that flags some rays has
+        # its last kernel look at every flag, and would count those the band before the last left behind.
+        r0 = Renderer(Scene.load(str(lone), 160, 90, 0))
+        band = []
+        for y0 in (30, 0, 45, 0, 30, 45, 40, 60, 45):
+            r0.reset_stats()
+            r0.render_tile(y0, 30)
+            band.append(r0.stats()["flagged_rays"])
+        r0.close()
+        assert band[0] > band[2] > 0 and band[1] == band[3] == band[7] == 0, (clear, band)
+        assert band[4] == band[0] and band[5] == band[8] == band[2], (clear, band)
+        r.reset_stats()
+        r.set_option(abi.RT_OPT_FRAMES_IN_FLIGHT, 4)
+        frames = [torch.zeros((90, 160, 4), dtype=torch.uint8, device="cuda") for _ in range(4)]
+        for k in range(8):
+            r.bind_frame(frames[k % 4])
+            r.render_frame()
+        torch.cuda.synchronize()
+        for f in frames:
+            assert np.array_equal(f.cpu().numpy().reshape(want.shape), want), clear
+        r.bind_frame(None)
+        r.set_option(abi.RT_OPT_FRAMES_IN_FLIGHT, 1)
+        seen[clear] = (counts[0], r.stats()["flagged_rays"], band)
+        r.close()
+    assert seen["0"] == seen["1"] and seen["0"][1] == 8 * seen["0"][0], seen

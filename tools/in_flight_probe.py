@@ -1,6 +1,6 @@
 """Milliseconds per 4K teapot frame (or one rank's share of it) against RT_OPT_FRAMES_IN_FLIGHT, brute force and LBVH.
 Usage: in_flight_probe.py [world ...]"""
-import sys, time
+import os, sys, time
 sys.path.insert(0, '.')
 import torch
 from raytracer_amd import Scene, abi
@@ -8,6 +8,8 @@ from raytracer_amd.render import Renderer
 sc = Scene.load('scenes/teapot.scene', 3840, 2160, 5)
 worlds = [int(a) for a in sys.argv[1:]] or [1, 8]
 r = Renderer(sc)
+if os.environ.get('SCAN_COPIES'):
+    r.set_option(abi.RT_OPT_SCAN_COPIES, 1)
 stream = torch.cuda.current_stream().cuda_stream
 frames = [torch.zeros((2160, 3840, 4), dtype=torch.uint8, device='cuda') for _ in range(8)]
 calls = [0]
