@@ -242,12 +242,11 @@ int rt_render_tile_noalloc(rt_ctx* c, int y0, int rows, void* stream) {
     Workspace ws;
     carve_workspace(&ws, base, pixels, levels, lights, c->aux_grid, 8, 0, false);
     // The array keeps whatever the previous call left in it, at whatever offsets that call's sizes
-    // put it: the one slice that must start at zero (the count of finished blocks behind the
-    // hit offsets) is cleared here; queue lengths, counters and flags are cleared by the pass.
+    // put it: queue lengths, counters and flags are cleared by the pass (a workspace struct that is new
+    // has the launch headers and flags filled before their first use).
     // (calls still in flight in lanes come first: pixels land in call order; a wait allocates nothing)
     for (Lane* L : c->lanes)
         if (L->pending) HIP_TRY(hipStreamWaitEvent(st, L->done, 0));
-    HIP_TRY(hipMemsetAsync(ws.hit_offsets, 0, ((size_t)c->aux_grid + 1) * sizeof(uint32_t), st));
     c->last_stream = st;
     PassDesc pd{y0, rows, rows, 0};
     return run_pass(c, ws, pd, rows, st, /*side_work=*/false);
@@ -347,12 +346,13 @@ int rt_bounce_probe(rt_ctx* c, int y0, int rows, double* point, double* refl, ui
         aux.vx = ab + 3 * ws.cap; aux.vy = ab + 4 * ws.cap; aux.vz = ab + 5 * ws.cap;
         HitArgs ha{};
         ha.sc = dsc; ha.cur = q[0]; ha.next = q[1]; ha.keys = ws.keys[0]; ha.next_keys = ws.keys[1];
-        ha.n_rays = ws.counts; ha.hit_offsets = ws.hit_offsets; ha.lvl = lvl; ha.aux = aux;
+        ha.n_rays = ws.counts; ha.n_hits = ws.counts + 1; ha.lvl = lvl; ha.aux = aux;
+        ha.hit_counts = ws.hit_counts;
         ha.occluded = ws.occluded[0]; ha.occl_words = words;
         ha.shadow_scan = scan_shadow ? ws.shadow_scan[0] : nullptr; ha.shadow_stride = (uint32_t)ws.cap;
         ha.light_frame = c->light_frame.p;
-        hipLaunchKernelGGL(k_hit_offsets, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, (const unsigned long long*)ws.keys[0],
-                           (const uint32_t*)ws.counts, ws.hit_offsets, ws.hit_offsets + c->aux_grid, ws.counts + 1);
+        hipLaunchKernelGGL(k_hit_counts, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, (const unsigned long long*)ws.keys[0],
+                           (const uint32_t*)ws.counts, ws.hit_counts);
         hipLaunchKernelGGL(k_hit, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, ha);
         HIP_TRY(hipGetLastError());
         if (c->hs.n_lights > 0) {

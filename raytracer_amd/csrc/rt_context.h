@@ -38,7 +38,7 @@ struct Workspace {
     int32_t *lvl_parent = nullptr, *lvl_obj = nullptr; // [levels][cap]
     double *lvl_phong = nullptr, *lvl_child = nullptr; // [levels][3][cap]
     uint32_t* counts = nullptr;                        // [levels + 2]
-    uint32_t* hit_offsets = nullptr;                   // [aux_grid + 1]: k_hit_offsets -> k_hit
+    uint32_t* hit_counts = nullptr;                    // [aux_grid]: k_hit_counts -> k_hit
     // Three launch headers (the pair list's fill counters, the task counter, ...) and two arrays of per-ray flags, which
     // the trace launches take in turn (RT_FLAGS_HEADER); one set per kind of query ([0] nearest hit, [1] shadow) so
     // that a level's shadow launches can run beside the next level's nearest-hit launches

@@ -2,7 +2,7 @@
 // rays (level 0 = camera rays, level k = k-th reflection).  Per level:
 //   nearest hit  of every ray in the level's queue  (k_filter<0> -> k_exact_pairs<0>, k_brute<0>)
 //   k_hit        compacts the rays that hit something, in the order of the rays
-//                (k_hit_offsets: hits per block -> offsets), computes hit point,
+//                (k_hit_counts: hits per block), computes hit point,
 //                normal and reflection, and writes the next level's ray queue
 //   shadow rays  one per (hit, light)               (k_filter<1> -> k_exact_pairs<1>, k_brute<1>)
 //   k_phong      Phong sum over the unshadowed lights

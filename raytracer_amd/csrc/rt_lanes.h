@@ -229,8 +229,6 @@ int ensure_lanes(rt_ctx* c, hipStream_t caller) {
         if (c->grid_hints && hipHostMalloc((void**)&L->hint, sizeof(PassHint), hipHostMallocDefault) != hipSuccess) { L->hint = nullptr; (void)hipGetLastError(); }
         if (L->hint) std::memset(L->hint, 0xff, sizeof(PassHint));
         L->ws.hint = L->hint;
-        e = hipMemset(L->ws.hit_offsets, 0, ((size_t)c->aux_grid + 1) * sizeof(uint32_t));
-        if (e != hipSuccess) return give_up(RT_ERR_DEVICE, std::string("frames in flight: ") + hipGetErrorString(e));
         c->lanes.push_back(L);
     }
     for (Lane* L : c->lanes) {

@@ -1,4 +1,4 @@
-// Between the trace launches of a level: compaction of the hits and the next level's rays (k_hit_offsets, k_hit),
+// Between the trace launches of a level: compaction of the hits and the next level's rays (k_hit_counts, k_hit),
 // Phong shading (k_phong), the deepest-first fold into the frame (k_fold), the ray counters (k_count).
 #pragma once
 
@@ -14,7 +14,8 @@ struct HitArgs {
     const unsigned long long* keys;
     unsigned long long* next_keys;
     const uint32_t* n_rays;
-    const uint32_t* hit_offsets;         // per block: hits of the blocks before it (k_hit_offsets, same grid)
+    uint32_t* n_hits;                    // out: the number of hits = the next queue's length
+    const uint32_t* hit_counts;          // per block: hits in its range of the queue (k_hit_counts, same grid)
     LevelStore lvl;
     HitAux aux;
     uint32_t* occluded;
@@ -28,81 +29,71 @@ struct HitArgs {
 // are neighbours on the film stay neighbours in the next level's queue and in the shadow
 // queue, which is what the bounding tests of k_filter live on (a task's 512 rays ask for few
 // triangles when they run close together).  Every block owns a contiguous range of the queue.
-// k_hit_offsets counts the hits per block; the block that finishes last turns the counts into
-// exclusive offsets and publishes the total as the next queue's length.
+// k_hit_counts counts the hits per range, nothing else; every block of k_hit (same grid) adds up the counts of the
+// ranges before its own, and the block of the last range publishes the total as the next queue's length.
+// (Earlier forms and what they cost: the counting kernel's last block -- found by a ticket behind a fence of device
+// scope per block -- turning the counts into offsets: 28 us per launch, most of it the 2048 tickets on one address and
+// the L2 write-backs of the fences.  One kernel with a look-back along per-block descriptors: a frame on its own
+// 1 % faster, four calls in flight 7 % slower -- blocks that wait for a predecessor another kernel's waves keep from
+// starting hold their wave slots while they wait.)
 __device__ __forceinline__ unsigned int hit_range_length(unsigned int n, unsigned int n_blocks) {
     const unsigned int per = (n + n_blocks - 1) / n_blocks;
     return (per + RT_BLOCK - 1) / RT_BLOCK * RT_BLOCK;
 }
 
 __global__ void __launch_bounds__(RT_BLOCK)
-k_hit_offsets(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ n_rays, uint32_t* offsets,
-              uint32_t* finished, uint32_t* n_hits) {
-    // offsets[0 .. gridDim.x): per block; *finished: blocks finished so far (zero between launches; a place of its
-    // own, whatever the grid: launches of different sizes share the offsets array)
-    __shared__ unsigned int part[RT_BLOCK];
-    __shared__ bool last_block;
-    const unsigned int n = *n_rays, G = gridDim.x;
-    const unsigned int per = hit_range_length(n, G);
+k_hit_counts(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ n_rays, uint32_t* __restrict__ counts) {
+    __shared__ unsigned int wave_hits[RT_BLOCK / RT_WAVE];
+    const unsigned int n = *n_rays;
+    const unsigned int per = hit_range_length(n, gridDim.x);
     const unsigned int begin = blockIdx.x * per;
     unsigned int mine = 0;
-    for (unsigned int it = 0; it < per; it += RT_BLOCK) {
+    for (unsigned int it = 0; it < per && begin + it < n; it += RT_BLOCK) {
         const unsigned int i = begin + it + threadIdx.x;
         if (i < n && keys[i] != RT_MISS_KEY) mine++;
     }
-    part[threadIdx.x] = mine;
+    for (int off = RT_WAVE / 2; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+    if ((threadIdx.x & (RT_WAVE - 1)) == 0) wave_hits[threadIdx.x / RT_WAVE] = mine;
     __syncthreads();
-    for (int off = RT_BLOCK / 2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
-        __syncthreads();
-    }
-    // Only blocks that own rays take part (a short queue must not cost a full grid's worth of
-    // atomics on one counter); an empty queue is block 0's to report.
-    const unsigned int active = (n + per - 1) / per;
-    if (n == 0) { if (blockIdx.x == 0 && threadIdx.x == 0) *n_hits = 0u; return; }
-    if (blockIdx.x >= active) return;
     if (threadIdx.x == 0) {
-        __hip_atomic_store(&offsets[blockIdx.x], part[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        last_block = atomicAdd(finished, 1u) == active - 1u;
+        unsigned int sum = 0;
+#pragma unroll
+        for (int w = 0; w < RT_BLOCK / RT_WAVE; w++) sum += wave_hits[w];
+        counts[blockIdx.x] = sum;                                     // (blocks without rays write 0)
     }
-    __syncthreads();
-    if (!last_block) return;
-    __threadfence();
-    // exclusive scan of the counts by this block: a run of consecutive entries per thread
-    const unsigned int run = (active + RT_BLOCK - 1) / RT_BLOCK;
-    const unsigned int first = threadIdx.x * run;
-    unsigned int sum = 0;
-    for (unsigned int k = first; k < first + run && k < active; k++)
-        sum += __hip_atomic_load(&offsets[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < RT_BLOCK; off <<= 1) {            // inclusive scan of the per-thread sums
-        unsigned int add = ((int)threadIdx.x >= off) ? part[threadIdx.x - off] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += add;
-        __syncthreads();
-    }
-    unsigned int at = part[threadIdx.x] - sum;
-    for (unsigned int k = first; k < first + run && k < active; k++) {
-        const unsigned int cnt = __hip_atomic_load(&offsets[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        offsets[k] = at;
-        at += cnt;
-    }
-    if (threadIdx.x == RT_BLOCK - 1) { *n_hits = part[RT_BLOCK - 1]; *finished = 0u; }
 }
 
 __global__ void __launch_bounds__(RT_BLOCK)
 k_hit(HitArgs A) {
     const DevScene* __restrict__ sc = A.sc;
     __shared__ unsigned int wave_hits[RT_BLOCK / RT_WAVE];
+    __shared__ unsigned int range_base;
     const unsigned int n = *A.n_rays;
     const int lane = threadIdx.x & (RT_WAVE - 1);
     const int wave = threadIdx.x / RT_WAVE;
     const unsigned int per = hit_range_length(n, gridDim.x);
     const unsigned int begin = blockIdx.x * per;
-    unsigned int block_base = A.hit_offsets[blockIdx.x];
+    // Only blocks that own rays take part; an empty queue is block 0's to report.
+    if (n == 0) { if (blockIdx.x == 0 && threadIdx.x == 0) *A.n_hits = 0u; return; }
+    const unsigned int active = (n + per - 1) / per;
+    if (blockIdx.x >= active) return;
+    {
+        // hits of the ranges before this one
+        unsigned int before = 0;
+        for (unsigned int k = threadIdx.x; k < blockIdx.x; k += RT_BLOCK) before += A.hit_counts[k];
+        for (int off = RT_WAVE / 2; off > 0; off >>= 1) before += __shfl_xor(before, off);
+        if (lane == 0) wave_hits[wave] = before;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned int sum = 0;
+#pragma unroll
+            for (int w = 0; w < RT_BLOCK / RT_WAVE; w++) sum += wave_hits[w];
+            range_base = sum;
+            if (blockIdx.x == active - 1u) *A.n_hits = sum + A.hit_counts[blockIdx.x];      // the next queue's length
+        }
+        __syncthreads();
+    }
+    unsigned int block_base = range_base;
     for (unsigned int it = 0; it < per && begin + it < n; it += RT_BLOCK) {
         const unsigned int i = begin + it + threadIdx.x;
         unsigned long long key = (i < n) ? A.keys[i] : RT_MISS_KEY;

