@@ -17,6 +17,8 @@ struct HitArgs {
     uint32_t* n_hits;                    // out: the number of hits = the next queue's length
     const uint32_t* hit_counts;          // per block: hits in its range of the queue (k_hit_counts, same grid)
     LevelStore lvl;
+    int32_t* parent_next;                // the level above's LevelStore::next (null: none kept, or the camera rays' level)
+    int32_t chain;                       // 1: keep the chains (LevelStore::next) for k_fold_all
     HitAux aux;
     uint32_t* occluded;
     int32_t occl_words;
@@ -191,6 +193,10 @@ k_hit(HitArgs A) {
         A.aux.vx[h] = rv.x; A.aux.vy[h] = rv.y; A.aux.vz[h] = rv.z;
         A.lvl.parent[h] = (int32_t)i;
         A.lvl.obj[h] = obj;
+        if (A.chain) {
+            A.lvl.next[h] = -1;
+            if (A.parent_next) A.parent_next[i] = (int32_t)h;
+        }
         for (int w = 0; w < A.occl_words; w++) A.occluded[(size_t)h * A.occl_words + w] = 0u;
     }
 }
@@ -207,6 +213,7 @@ struct PhongArgs {
     int32_t occl_words;
     uint32_t cap;                        // stride of lvl.phong / lvl.child component planes
     const uint32_t* n_hits;
+    int32_t init_child;                  // 1: the fold goes level by level and wants lvl.child at zero
 };
 
 __global__ void __launch_bounds__(RT_BLOCK)
@@ -244,7 +251,7 @@ k_phong(PhongArgs A) {
             total = add3(total, mul3(intensity, coeffs));
         }
         A.lvl.phong[h] = total.x; A.lvl.phong[h + (size_t)A.cap] = total.y; A.lvl.phong[h + 2 * (size_t)A.cap] = total.z;
-        A.lvl.child[h] = 0.0; A.lvl.child[h + (size_t)A.cap] = 0.0; A.lvl.child[h + 2 * (size_t)A.cap] = 0.0;
+        if (A.init_child) { A.lvl.child[h] = 0.0; A.lvl.child[h + (size_t)A.cap] = 0.0; A.lvl.child[h + 2 * (size_t)A.cap] = 0.0; }
     }
 }
 
@@ -292,10 +299,27 @@ k_fold(FoldArgs A) {
     }
 }
 
-// Adds one pass's queue lengths to the running counters.
-__global__ void k_count(const DevScene* __restrict__ sc, const uint32_t* __restrict__ counts, int levels,
-                        DevCounters* __restrict__ c) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+// The whole fold in one launch, for scenes of at most RT_FOLD_MAX_LEVELS levels: a thread per hit of a camera ray walks
+// down the chain of reflected hits (LevelStore::next) and folds it from its deepest hit up -- the same additions and
+// multiplications in the same order as the level-by-level fold (a hit without a reflected hit takes 0 for it,
+// raytracer.cpp:542-543).  Compaction keeps the order of the rays, so neighbouring threads read neighbouring entries
+// at every level.  Block 0 also does what k_count does.
+struct FoldAllArgs {
+    const DevScene* sc;
+    const int32_t* parent;               // [levels][cap]
+    const int32_t* obj;                  // [levels][cap]
+    const double* phong;                 // [levels][3][cap]
+    const int32_t* next;                 // level k at next + k * 6 * cap (see LevelStore::next)
+    uint32_t cap;
+    int32_t levels;
+    const uint32_t* counts;              // counts[k + 1]: hits of level k
+    const int32_t* pixel_of_ray;
+    uint32_t* frame;
+    DevCounters* counters;
+};
+
+__device__ __forceinline__ void count_pass(const DevScene* __restrict__ sc, const uint32_t* __restrict__ counts, int levels,
+                                           DevCounters* __restrict__ c) {
     unsigned long long prims = (unsigned long long)sc->n_prims_nominal;
     unsigned long long rays = 0, hits = 0;
     for (int k = 0; k < levels; k++) { rays += counts[k]; hits += counts[k + 1]; }
@@ -306,5 +330,50 @@ __global__ void k_count(const DevScene* __restrict__ sc, const uint32_t* __restr
     atomicAdd(&c->hits, hits);
     atomicAdd(&c->closest_tests, rays * prims);
     atomicAdd(&c->anyhit_tests, hits * (unsigned long long)sc->n_lights * prims);
+}
+
+__global__ void __launch_bounds__(RT_BLOCK)
+k_fold_all(FoldAllArgs A) {
+    const DevScene* __restrict__ sc = A.sc;
+    if (blockIdx.x == 0 && threadIdx.x == 0) count_pass(sc, A.counts, A.levels, A.counters);
+    const unsigned int n = A.counts[1];
+    const size_t cap = A.cap;
+    for (unsigned int h0 = blockIdx.x * blockDim.x + threadIdx.x; h0 < n; h0 += gridDim.x * blockDim.x) {
+        int at[RT_FOLD_MAX_LEVELS];
+        at[0] = (int)h0;
+        int deepest = 0;
+        bool on = true;
+#pragma unroll
+        for (int k = 0; k + 1 < RT_FOLD_MAX_LEVELS; k++) {
+            at[k + 1] = 0;
+            if (on && k + 1 < A.levels) {
+                const int down = A.next[(size_t)k * 6 * cap + (size_t)at[k]];
+                on = down >= 0;
+                if (on) { at[k + 1] = down; deepest = k + 1; }
+            } else {
+                on = false;
+            }
+        }
+        d3 val = mk3(0.0, 0.0, 0.0);
+#pragma unroll
+        for (int k = RT_FOLD_MAX_LEVELS - 1; k >= 0; k--) {
+            if (k <= deepest) {
+                const size_t h = (size_t)at[k];
+                const DevMaterial& m = sc->materials[sc->obj_material[A.obj[(size_t)k * cap + h]]];
+                const double* ph = A.phong + (size_t)k * 3 * cap;
+                const d3 phong = mk3(ph[h], ph[h + cap], ph[h + 2 * cap]);
+                val = add3(phong, mul3(val, ld3(m.kr)));     // raytracer.cpp:542-543
+            }
+        }
+        A.frame[A.pixel_of_ray[A.parent[h0]]] =
+            quantise(val.x) | (quantise(val.y) << 8) | (quantise(val.z) << 16) | 0xff000000u;
+    }
+}
+
+// Adds one pass's queue lengths to the running counters.
+__global__ void k_count(const DevScene* __restrict__ sc, const uint32_t* __restrict__ counts, int levels,
+                        DevCounters* __restrict__ c) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    count_pass(sc, counts, levels, c);
 }
 

@@ -290,6 +290,8 @@ int run_pass(rt_ctx* c, const Workspace& ws, PassDesc pd, int nrows, hipStream_t
     hipEvent_t* ev_hit = c->cur ? c->cur->ev_hit.data() : c->ev_hit.data();
     hipEvent_t* ev_phong = c->cur ? c->cur->ev_phong.data() : c->ev_phong.data();
     hipStream_t sb = overlap ? side : st;
+    // (the fold: one launch along the chains of reflected hits, or, for deep scenes, level by level)
+    const bool chain = levels <= RT_FOLD_MAX_LEVELS && !c->fold_by_level;
     for (int k = 0; k < levels; k++) {
         const int cur = k & 1, nxt = cur ^ 1;
         LevelStore lvl = level_of(ws, k);
@@ -311,6 +313,8 @@ int run_pass(rt_ctx* c, const Workspace& ws, PassDesc pd, int nrows, hipStream_t
         ha.sc = dsc; ha.cur = q[cur]; ha.next = q[nxt]; ha.keys = ws.keys[cur]; ha.next_keys = ws.keys[nxt];
         ha.n_rays = ws.counts + k; ha.n_hits = ws.counts + k + 1; ha.lvl = lvl; ha.aux = aux;
         ha.hit_counts = ws.hit_counts;
+        ha.chain = chain ? 1 : 0;
+        ha.parent_next = (chain && k > 0) ? level_of(ws, k - 1).next : nullptr;
         ha.occluded = occl; ha.occl_words = ws.occl_words;
         ha.shadow_scan = scan_shadow ? ws.shadow_scan[cur] : nullptr; ha.shadow_stride = (uint32_t)ws.cap;
         ha.light_frame = c->light_frame.p;
@@ -336,22 +340,32 @@ int run_pass(rt_ctx* c, const Workspace& ws, PassDesc pd, int nrows, hipStream_t
         PhongArgs pa{};
         pa.sc = dsc; pa.next = q[nxt]; pa.aux = aux; pa.lvl = lvl; pa.occluded = occl;
         pa.occl_words = ws.occl_words; pa.cap = (uint32_t)ws.cap; pa.n_hits = ws.counts + k + 1;
+        pa.init_child = chain ? 0 : 1;
         hipLaunchKernelGGL(k_phong, dim3(hits_grid), dim3(RT_BLOCK), 0, sb, pa);
         HIP_TRY(hipGetLastError());
         if (overlap) HIP_TRY(hipEventRecord(ev_phong[k], sb));
     }
     // the fold (and whatever the caller enqueues next) comes after everything on the side stream
     if (overlap) HIP_TRY(hipStreamWaitEvent(st, ev_phong[levels - 1], 0));
-    for (int k = levels - 1; k >= 0; k--) {
-        FoldArgs fa{};
-        fa.sc = dsc; fa.lvl = level_of(ws, k); fa.parent_lvl = level_of(ws, k > 0 ? k - 1 : 0);
-        fa.cap = (uint32_t)ws.cap; fa.n_hits = ws.counts + k + 1; fa.level = k;
-        fa.pixel_of_ray = ws.pixel_of_ray; fa.frame = c->frame;
-        hipLaunchKernelGGL(k_fold, dim3(blocks_for(c, expected(k + 1))), dim3(RT_BLOCK), 0, st, fa);
+    if (chain) {
+        FoldAllArgs fa{};
+        fa.sc = dsc; fa.parent = ws.lvl_parent; fa.obj = ws.lvl_obj; fa.phong = ws.lvl_phong; fa.next = (const int32_t*)ws.lvl_child;
+        fa.cap = (uint32_t)ws.cap; fa.levels = levels; fa.counts = ws.counts;
+        fa.pixel_of_ray = ws.pixel_of_ray; fa.frame = c->frame; fa.counters = c->counters.p;
+        hipLaunchKernelGGL(k_fold_all, dim3(blocks_for(c, expected(1))), dim3(RT_BLOCK), 0, st, fa);
+        HIP_TRY(hipGetLastError());
+    } else {
+        for (int k = levels - 1; k >= 0; k--) {
+            FoldArgs fa{};
+            fa.sc = dsc; fa.lvl = level_of(ws, k); fa.parent_lvl = level_of(ws, k > 0 ? k - 1 : 0);
+            fa.cap = (uint32_t)ws.cap; fa.n_hits = ws.counts + k + 1; fa.level = k;
+            fa.pixel_of_ray = ws.pixel_of_ray; fa.frame = c->frame;
+            hipLaunchKernelGGL(k_fold, dim3(blocks_for(c, expected(k + 1))), dim3(RT_BLOCK), 0, st, fa);
+            HIP_TRY(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_count, dim3(1), dim3(64), 0, st, dsc, (const uint32_t*)ws.counts, levels, c->counters.p);
         HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_count, dim3(1), dim3(64), 0, st, dsc, (const uint32_t*)ws.counts, levels, c->counters.p);
-    HIP_TRY(hipGetLastError());
     // this pass's queue lengths for the next pass of its size (pinned memory: the copy is a device-side write)
     if (c->grid_hints && ws.hint && levels + 2 <= 72) {
         ws.hint->n_pix = n_pix;

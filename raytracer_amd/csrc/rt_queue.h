@@ -86,8 +86,11 @@ struct LevelStore {             // one entry per hit of a level
     int32_t* parent;            // index of the ray in this level's queue (= hit index one level up, or the pixel)
     int32_t* obj;               // Scene::objects index that was hit
     double* phong;              // [3][cap] phongShade result
-    double* child;              // [3][cap] value returned by the reflected ray (0 when it misses)
+    double* child;              // [3][cap] value returned by the reflected ray (0 when it misses): the level-by-level fold
+    int32_t* next;              // the hit of this hit's reflected ray one level down, or -1 (the same memory as `child`:
+                                // the fold that walks the chains needs no stored child values)
 };
+#define RT_FOLD_MAX_LEVELS 8    // deepest chain k_fold_all walks (deeper scenes fold level by level)
 
 struct HitAux {                 // per hit of the current level only
     double *nx, *ny, *nz;       // shading normal

@@ -937,6 +937,7 @@ static int upload_scene(rt_ctx** out, const rt_scene_desc* d) {
 #undef RT_GRID_OF
     c->aux_grid = c->n_cu * 8;
     if (const char* env = std::getenv("RAYTRACER_AMD_GRID_HINTS")) c->grid_hints = std::atoi(env) ? 1 : 0;
+    if (const char* env = std::getenv("RAYTRACER_AMD_FOLD_BY_LEVEL")) c->fold_by_level = std::atoi(env) != 0;
     if (const char* env = std::getenv("RAYTRACER_AMD_BESIDE_DIV")) c->beside_grid_div = std::max(1, std::min(16, std::atoi(env)));
     // this device's copy of the static workspace (for rt_render_tile_noalloc)
     if (int rc = resolve_scratch(c->device)) return bail(rc);

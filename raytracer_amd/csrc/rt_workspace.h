@@ -22,6 +22,7 @@ LevelStore level_of(const Workspace& w, int k) {
     l.obj = w.lvl_obj + (size_t)k * w.cap;
     l.phong = w.lvl_phong + (size_t)k * 3 * w.cap;
     l.child = w.lvl_child + (size_t)k * 3 * w.cap;
+    l.next = (int32_t*)l.child;
     return l;
 }
 

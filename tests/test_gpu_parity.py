@@ -522,3 +522,37 @@ def test_slot_order_changes_nothing(tmp_path, monkeypatch):
         got[order] = st["exact_tests"]
     # the upload's own choice for a shuffled mesh is the curve (compact clusters list the pairs the curve order lists)
     assert got[""] == got["curve"]
+
+
+@pytest.mark.parametrize("name,w,h,depth", [
+    ("teapot.scene", 320, 180, 5), ("mixed_xf.scene", 200, 150, 7), ("scene3.scene", 160, 120, 2), ("teapot.scene", 160, 90, 9),
+])
+def test_the_two_folds_agree(name, w, h, depth, monkeypatch):
+    """The colours are folded deepest level first (raytracer.cpp:542-543) either along each camera ray's chain of
+    reflected hits in one launch (scenes of at most eight levels) or level by level; the same additions and
+    multiplications in the same order, so the same frame -- also with several calls in flight and through the LBVH.
+    (Depth 9 has ten levels and takes the level-by-level fold either way: that leg pins the fallback.)"""
+    from raytracer_amd.render import Renderer
+    sc = Scene.load(os.path.join(ROOT, "scenes", name), w, h, depth)
+    frames = {}
+    for by_level in ("1", "0"):
+        monkeypatch.setenv("RAYTRACER_AMD_FOLD_BY_LEVEL", by_level)
+        r = Renderer(sc)
+        r.render_frame()
+        frames[by_level] = [r.download()]
+        st = r.stats()
+        r.set_option(abi.RT_OPT_USE_BVH, 1)
+        r.render_frame()
+        frames[by_level].append(r.download())
+        r.set_option(abi.RT_OPT_USE_BVH, 0)
+        r.set_option(abi.RT_OPT_FRAMES_IN_FLIGHT, 3)
+        for _ in range(4):
+            r.render_frame()
+        frames[by_level].append(r.download())
+        r.set_option(abi.RT_OPT_FRAMES_IN_FLIGHT, 1)
+        frames[by_level].append((st["rays_primary"], st["rays_reflect"], st["rays_shadow"], st["hits"]))
+        r.close()
+    for a, b in zip(frames["1"][:3], frames["0"][:3]):
+        assert np.array_equal(a, b), int((a != b).any(axis=-1).sum())
+    assert frames["1"][3] == frames["0"][3]
+    assert np.array_equal(frames["0"][0], frames["0"][2])
