@@ -273,11 +273,10 @@ int rt_primary_hits(rt_ctx* c, int y0, int rows, uint64_t* keys, size_t count) {
         const int nrows = std::min(rows_per_pass, rows - q0);
         const int n_pix = nrows * W;
         PassDesc pd{y0, rows, rows, q0};
-        HIP_TRY(hipMemsetAsync(ws.counts, 0, (ws.levels + 2) * sizeof(uint32_t), st));
         const bool scan = keeps_scan_copies(c, ws);
         RayQueue q = queue_of(ws, 0, scan);
         hipLaunchKernelGGL(k_primary, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, dsc, pd, n_pix, q, ws.keys[0],
-                           ws.pixel_of_ray, c->frame, ws.counts);
+                           ws.pixel_of_ray, c->frame, ws.counts, ws.levels + 2);
         HIP_TRY(hipGetLastError());
         TraceArgs ta{};
         ta.rays = q; ta.n_items = ws.counts; ta.keys = ws.keys[0]; ta.occl_words = ws.occl_words;
@@ -328,11 +327,10 @@ int rt_bounce_probe(rt_ctx* c, int y0, int rows, double* point, double* refl, ui
         const int nrows = std::min(rows_per_pass, rows - q0);
         const int n_pix = nrows * W;
         PassDesc pd{y0, rows, rows, q0};
-        HIP_TRY(hipMemsetAsync(ws.counts, 0, (ws.levels + 2) * sizeof(uint32_t), st));
         const bool scan = keeps_scan_copies(c, ws), scan_shadow = scan && keeps_shadow_copies(c, ws);
         RayQueue q[2] = {queue_of(ws, 0, scan), queue_of(ws, 1, scan)};
         hipLaunchKernelGGL(k_primary, dim3(c->aux_grid), dim3(RT_BLOCK), 0, st, dsc, pd, n_pix, q[0], ws.keys[0],
-                           ws.pixel_of_ray, c->frame, ws.counts);
+                           ws.pixel_of_ray, c->frame, ws.counts, ws.levels + 2);
         HIP_TRY(hipGetLastError());
         TraceArgs ta{};
         ta.rays = q[0]; ta.n_items = ws.counts; ta.keys = ws.keys[0]; ta.occl_words = words;

@@ -316,10 +316,16 @@ struct FoldAllArgs {
     const int32_t* pixel_of_ray;
     uint32_t* frame;
     DevCounters* counters;
+    uint32_t* hint;                      // pinned host memory for the pass's queue lengths ([levels + 2]), or null
 };
 
+// `hint`: the queue lengths also go to pinned host memory, for the launch geometry of the next pass of this size
+// (written from here, no copy behind the pass: a copy to the host ends in a release of system scope, which
+// writes the L2 back under everything else that is running).
 __device__ __forceinline__ void count_pass(const DevScene* __restrict__ sc, const uint32_t* __restrict__ counts, int levels,
-                                           DevCounters* __restrict__ c) {
+                                           DevCounters* __restrict__ c, uint32_t* hint) {
+    if (hint)
+        for (int k = 0; k < levels + 2; k++) __hip_atomic_store(&hint[k], counts[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     unsigned long long prims = (unsigned long long)sc->n_prims_nominal;
     unsigned long long rays = 0, hits = 0;
     for (int k = 0; k < levels; k++) { rays += counts[k]; hits += counts[k + 1]; }
@@ -335,7 +341,7 @@ __device__ __forceinline__ void count_pass(const DevScene* __restrict__ sc, cons
 __global__ void __launch_bounds__(RT_BLOCK)
 k_fold_all(FoldAllArgs A) {
     const DevScene* __restrict__ sc = A.sc;
-    if (blockIdx.x == 0 && threadIdx.x == 0) count_pass(sc, A.counts, A.levels, A.counters);
+    if (blockIdx.x == 0 && threadIdx.x == 0) count_pass(sc, A.counts, A.levels, A.counters, A.hint);
     const unsigned int n = A.counts[1];
     const size_t cap = A.cap;
     for (unsigned int h0 = blockIdx.x * blockDim.x + threadIdx.x; h0 < n; h0 += gridDim.x * blockDim.x) {
@@ -372,8 +378,8 @@ k_fold_all(FoldAllArgs A) {
 
 // Adds one pass's queue lengths to the running counters.
 __global__ void k_count(const DevScene* __restrict__ sc, const uint32_t* __restrict__ counts, int levels,
-                        DevCounters* __restrict__ c) {
+                        DevCounters* __restrict__ c, uint32_t* hint) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    count_pass(sc, counts, levels, c);
+    count_pass(sc, counts, levels, c, hint);
 }
 

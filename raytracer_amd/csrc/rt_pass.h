@@ -265,13 +265,12 @@ int run_pass(rt_ctx* c, const Workspace& ws, PassDesc pd, int nrows, hipStream_t
     const int n_pix = nrows * W;
     const int levels = ws.levels;
     const DevScene* dsc = c->d_scene.p;
-    HIP_TRY(hipMemsetAsync(ws.counts, 0, (levels + 2) * sizeof(uint32_t), st));
     // FP32 scan copies of the rays for the bounded scans (RayQueue::scan): written by k_primary / k_hit when the
     // workspace has room for them and the scans that read them will run
     const bool scan = keeps_scan_copies(c, ws), scan_shadow = scan && keeps_shadow_copies(c, ws);
     RayQueue q[2] = {queue_of(ws, 0, scan), queue_of(ws, 1, scan)};
     hipLaunchKernelGGL(k_primary, dim3(blocks_for(c, (size_t)n_pix)), dim3(RT_BLOCK), 0, st, dsc, pd, n_pix, q[0], ws.keys[0],
-                       ws.pixel_of_ray, c->frame, ws.counts);
+                       ws.pixel_of_ray, c->frame, ws.counts, ws.levels + 2);
     HIP_TRY(hipGetLastError());
     // Queue lengths of the last pass of this size in this workspace (see PassHint), a quarter on top; none: the pass's pixels
     const bool hinted = c->grid_hints && ws.hint && ws.hint->n_pix == n_pix && ws.hint->counts[0] == (uint32_t)n_pix && levels + 2 <= 72;
@@ -347,8 +346,15 @@ int run_pass(rt_ctx* c, const Workspace& ws, PassDesc pd, int nrows, hipStream_t
     }
     // the fold (and whatever the caller enqueues next) comes after everything on the side stream
     if (overlap) HIP_TRY(hipStreamWaitEvent(st, ev_phong[levels - 1], 0));
+    // this pass's queue lengths for the next pass of its size: written to pinned memory by the kernel that counts
+    uint32_t* hint_counts = nullptr;
+    if (c->grid_hints && ws.hint && levels + 2 <= 72) {
+        ws.hint->n_pix = n_pix;
+        hint_counts = ws.hint->counts;
+    }
     if (chain) {
         FoldAllArgs fa{};
+        fa.hint = hint_counts;
         fa.sc = dsc; fa.parent = ws.lvl_parent; fa.obj = ws.lvl_obj; fa.phong = ws.lvl_phong; fa.next = (const int32_t*)ws.lvl_child;
         fa.cap = (uint32_t)ws.cap; fa.levels = levels; fa.counts = ws.counts;
         fa.pixel_of_ray = ws.pixel_of_ray; fa.frame = c->frame; fa.counters = c->counters.p;
@@ -363,13 +369,8 @@ int run_pass(rt_ctx* c, const Workspace& ws, PassDesc pd, int nrows, hipStream_t
             hipLaunchKernelGGL(k_fold, dim3(blocks_for(c, expected(k + 1))), dim3(RT_BLOCK), 0, st, fa);
             HIP_TRY(hipGetLastError());
         }
-        hipLaunchKernelGGL(k_count, dim3(1), dim3(64), 0, st, dsc, (const uint32_t*)ws.counts, levels, c->counters.p);
+        hipLaunchKernelGGL(k_count, dim3(1), dim3(64), 0, st, dsc, (const uint32_t*)ws.counts, levels, c->counters.p, hint_counts);
         HIP_TRY(hipGetLastError());
-    }
-    // this pass's queue lengths for the next pass of its size (pinned memory: the copy is a device-side write)
-    if (c->grid_hints && ws.hint && levels + 2 <= 72) {
-        ws.hint->n_pix = n_pix;
-        HIP_TRY(hipMemcpyAsync(ws.hint->counts, ws.counts, (size_t)(levels + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     }
     return 0;
 }

@@ -139,7 +139,7 @@ __host__ __device__ __forceinline__ void queue_pixel(int p, int W, int rows, int
 __global__ void __launch_bounds__(RT_BLOCK)
 k_primary(const DevScene* __restrict__ sc, PassDesc pd, int n_pix, RayQueue q,
           unsigned long long* __restrict__ keys, int32_t* __restrict__ pixel_of_ray,
-          uint32_t* __restrict__ frame, uint32_t* __restrict__ counts) {
+          uint32_t* __restrict__ frame, uint32_t* __restrict__ counts, int n_counts) {
     int W = sc->width, H = sc->height;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n_pix; p += gridDim.x * blockDim.x) {
         int row, x;
@@ -166,6 +166,10 @@ k_primary(const DevScene* __restrict__ sc, PassDesc pd, int n_pix, RayQueue q,
         pixel_of_ray[p] = pix;
         frame[pix] = 0xff000000u;               // R,G,B = 0, alpha = 255
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) counts[0] = (uint32_t)n_pix;
+    // the pass's queue lengths: this queue's, and zero for the levels below until their rays are counted
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        counts[0] = (uint32_t)n_pix;
+        for (int k = 1; k < n_counts; k++) counts[k] = 0u;
+    }
 }
 
