@@ -10,6 +10,8 @@ worlds = [int(a) for a in sys.argv[1:]] or [1, 8]
 r = Renderer(sc)
 if os.environ.get('SCAN_COPIES'):
     r.set_option(abi.RT_OPT_SCAN_COPIES, 1)
+if os.environ.get('OVERLAP'):
+    r.set_option(abi.RT_OPT_OVERLAP, int(os.environ['OVERLAP']))
 stream = torch.cuda.current_stream().cuda_stream
 frames = [torch.zeros((2160, 3840, 4), dtype=torch.uint8, device='cuda') for _ in range(8)]
 calls = [0]
