@@ -97,11 +97,13 @@ typedef enum rt_option {
                                 (RT_OPT_BVH_PLANE_GUARD).  Blocks (build, and one calibration frame).
                                 The traversal walks four-wide nodes (each binary node with its internal children
                                 replaced by theirs); 2: walk the binary tree itself (same frames, ~15 % slower) */
-    RT_OPT_FILTER_FORM = 5,  /* form of the FP32 candidate filter: 0 = chosen from the scene when it was
-                                uploaded (default), 1 = static worst-case margins (cheapest test), 2 = per-test
-                                margins (one more instruction per test; for meshes of triangles that are
-                                tiny against the scene, or with many triangles in one plane).  Frames are
-                                identical in every form; blocks until queued work has finished */
+    RT_OPT_FILTER_FORM = 5,  /* form of the FP32 candidate filter: 0 = chosen from the scene's own numbers
+                                (default; chosen again when RT_OPT_BOUNDING_TESTS changes: with bounding tests few
+                                pairs reach the triangle test and per-test margins pay as soon as the static ones
+                                are a few per cent of a triangle's width), 1 = static worst-case margins (cheapest
+                                test), 2 = per-test margins (one more instruction per test; fewer pairs listed for
+                                the reference-precision re-test).  Frames are identical in every form; blocks until
+                                queued work has finished */
     RT_OPT_SHARED_CONSTANTS = 6, /* 1 (default): the brute-force filter reads host-computed per-triangle constants
                                 where all rays of a launch share their origin (camera rays) or their direction
                                 (shadow rays towards a directional light); 0: every ray is treated alike */

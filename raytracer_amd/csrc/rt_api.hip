@@ -87,6 +87,18 @@ extern "C" {
 // RT_OPT_BVH_PLANE_GUARD = 2: one whole frame through the LBVH with the in-plane-origin scan behind every traversal,
 // into the context's own frame buffer, its counts kept out of the statistics.  The scan stays on iff some pair of that
 // frame took the in-plane-origin branch of Triangle::intersection (raytracer.cpp:319-321).
+// Installs the form of the filter the options now ask for, if it is not the one installed (and rebuilds the LBVH over
+// the new slot order when the context uses one).
+static int reinstall_form(rt_ctx* c) {
+    const int want = chosen_form(c);
+    if (want == c->robust) return 0;
+    const int had_bvh = c->use_bvh;
+    int rc = install_filter(c, want);
+    if (rc) return rc;
+    if (had_bvh) return build_bvh(c);
+    return 0;
+}
+
 static int calibrate_bvh_guard(rt_ctx* c) {
     if (c->bvh_guard_mode != 2) { c->bvh_guard = c->bvh_guard_mode; return 0; }
     if (c->bvh_guard_calibrated) { c->bvh_guard = c->bvh_guard_found ? 1 : 0; return 0; }
@@ -135,13 +147,8 @@ int rt_set_option(rt_ctx* c, int option, int64_t value) {
             return 0;
         case RT_OPT_FILTER_FORM: {
             if (value < 0 || value > 2) return fail(RT_ERR_ARG, "rt_set_option: filter form is 0 (auto), 1 (static) or 2 (per-test)");
-            const int want = value == 0 ? c->auto_robust : (value == 2 ? 1 : 0);
-            if (want == c->robust) return 0;
-            const int had_bvh = c->use_bvh;
-            int rc = install_filter(c, want);
-            if (rc) return rc;
-            if (had_bvh) return build_bvh(c);
-            return 0;
+            c->form_option = (int)value;
+            return reinstall_form(c);
         }
         case RT_OPT_SHARED_CONSTANTS: c->shared_consts = value ? 1 : 0; return 0;
         case RT_OPT_OVERLAP: c->overlap = value ? 1 : 0; return 0;
@@ -167,7 +174,9 @@ int rt_set_option(rt_ctx* c, int option, int64_t value) {
             c->bvh_guard = value == 2 ? 1 : (int)value;
             if (c->use_bvh) return calibrate_bvh_guard(c);
             return 0;
-        case RT_OPT_BOUNDING_TESTS: c->pretest = value ? 1 : 0; c->pretest_any = value == 1 ? 1 : 0; return 0;
+        case RT_OPT_BOUNDING_TESTS:
+            c->pretest = value ? 1 : 0; c->pretest_any = value == 1 ? 1 : 0;
+            return reinstall_form(c);          // (the form chosen for a scan without bounding tests may be the other one)
         case RT_OPT_USE_BVH:
             if (value) {
                 HIP_TRY(hipSetDevice(c->device));

@@ -133,7 +133,13 @@ struct rt_ctx {
     std::vector<int32_t> h_xf_ident;
     std::vector<double> h_xf;             // [n_transforms][48]
     int clock_khz = 0;                    // engine clock reported by the runtime
-    int auto_robust = 0;                  // the form chosen from the scene's own numbers
+    // The form of the filter chosen from the scene's own numbers, per configuration: where every pair takes the
+    // triangle test (no bounding tests) the static margins save a multiply-add per ray and triangle unless they are
+    // useless; where bounding tests decide most pairs, few triangle tests are left and the per-test margins pay as
+    // soon as the static ones list a few per cent of pairs too many for the reference-precision re-test.
+    int auto_robust = 0;                  // ... without bounding tests
+    int auto_robust_bounded = 0;          // ... with them (RT_OPT_BOUNDING_TESTS, the default)
+    int form_option = 0;                  // RT_OPT_FILTER_FORM as last set: 0 = chosen here, 1 static, 2 per-test
     int robust = 0;                       // the form installed now
 
     // per-triangle constants shared by all rays of a launch (see filter_z2)

@@ -128,10 +128,14 @@ __device__ __forceinline__ void filter_in_plane2(const v16f f, v2f px, v2f py, v
         a = __builtin_elementwise_fma(-n1, py, a);
         a = __builtin_elementwise_fma(-n2, pz, a);
     }
-    bool g0 = true, g1 = true;
-    if (ROBUST && SHARED == 2) {
+    // The branch is the reference's only for a grazing ray, |b| < eps (raytracer.cpp:319), and b_hi lies above eps by
+    // more than the FP32 b can be off: a ray that is not grazing goes by the other terms alone.  (Without this every
+    // ray that leaves a surface lists the triangle it starts on and that triangle's coplanar neighbours: two thirds
+    // of all listed pairs of the benchmark frame.)
+    bool g0, g1;
+    if (SHARED == 2) {
         g0 = g1 = !(fabsf(shared) * Q.b_hi < 1.0f);                 // |b| <= b_hi, or NaN
-    } else if (ROBUST) {
+    } else {
         v2f b = n0 * vx;
         b = __builtin_elementwise_fma(n1, vy, b);
         b = __builtin_elementwise_fma(n2, vz, b);

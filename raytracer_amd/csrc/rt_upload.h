@@ -44,6 +44,12 @@ void bounding_cone(Vec apex, Vec centre, double radius, float out[4]) {
 // Orders the triangles for the chosen form of the filter (regular ones by transform group and
 // dominant axis, then the irregular ones), builds the groups, and uploads the triangle records,
 // the groups and the scene header.  Called by rt_upload_scene and by RT_OPT_FILTER_FORM.
+// The form the context should have installed now (see rt_ctx::auto_robust).
+int chosen_form(const rt_ctx* c) {
+    if (c->form_option) return c->form_option == 2 ? 1 : 0;
+    return c->pretest ? c->auto_robust_bounded : c->auto_robust;
+}
+
 int install_filter(rt_ctx* c, int robust) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());          // no launch may still read the records replaced here
@@ -867,6 +873,11 @@ static int upload_scene(rt_ctx** out, const rt_scene_desc* d) {
         }
         const double mean_margin = n_ok ? sum / (double)n_ok : 0.0;
         c->auto_robust = (n_only_robust > 0 || mean_margin > 1.0 || largest_plane > 16) ? 1 : 0;
+        // (2 % of a triangle's width per edge: the benchmark's teapot has 7 %, and its frame lists 21 M pairs with the
+        // static margins, 14 M with the per-test ones, of which the reference accepts 11 M)
+        c->auto_robust_bounded = (c->auto_robust || mean_margin > 0.02) ? 1 : 0;
+        if (timing) fprintf(stderr, "  filter form: mean static margin %.4f of a triangle, %zu triangles only regular with per-test margins, largest plane %d triangles\n",
+                            mean_margin, n_only_robust, largest_plane);
     }
 
     std::vector<DevMaterial> mats(d->n_materials);
@@ -908,7 +919,7 @@ static int upload_scene(rt_ctx** out, const rt_scene_desc* d) {
 
     lap("form choice + small uploads");
     // triangle records, groups and the scene header, in the form chosen above
-    if (int rc = install_filter(c, c->auto_robust)) return bail(rc);
+    if (int rc = install_filter(c, chosen_form(c))) return bail(rc);
     lap("install_filter");
     hipError_t e = c->own_frame.alloc((size_t)d->width * d->height);
     if (e != hipSuccess) return bail(fail(RT_ERR_DEVICE, std::string("frame: ") + hipGetErrorString(e)));

@@ -232,8 +232,30 @@ def test_work_counters_change_nothing_and_add_up(name, w, h, depth):
 def test_filter_form_follows_the_scene():
     """Large smooth triangles take the cheap static margins; a mesh of triangles that are tiny
     against its scene, or that has walls of coplanar triangles, takes per-test margins and then
-    lists only a few pairs per ray instead of overflowing into the full scan."""
-    _, st = gpu_render(Scene.load(scene_file("teapot"), 96, 54, 2))
+    lists only a few pairs per ray instead of overflowing into the full scan.  In between -- the teapot, whose static
+    margins are some per cent of a triangle -- the choice follows the configuration: per-test margins where bounding
+    tests decide most pairs (fewer pairs for the re-test), static ones where every pair takes the triangle test."""
+    from raytracer_amd.render import Renderer
+    r = Renderer(Scene.load(scene_file("teapot"), 96, 54, 2))
+    r.render_frame()
+    bounded, st = r.download(), r.stats()
+    assert st["filter_form"] == 2 and st["flagged_rays"] == 0
+    listed_per_test = st["exact_tests"]
+    r.set_option(abi.RT_OPT_BOUNDING_TESTS, 0)
+    r.reset_stats()
+    r.render_frame()
+    st = r.stats()
+    assert st["filter_form"] == 1 and st["flagged_rays"] == 0 and np.array_equal(r.download(), bounded)
+    assert st["exact_tests"] > listed_per_test
+    r.set_option(abi.RT_OPT_FILTER_FORM, 1)          # ... and the explicit choice stays when the configuration changes
+    r.set_option(abi.RT_OPT_BOUNDING_TESTS, 1)
+    r.render_frame()
+    assert r.stats()["filter_form"] == 1 and np.array_equal(r.download(), bounded)
+    r.set_option(abi.RT_OPT_FILTER_FORM, 0)
+    r.render_frame()
+    assert r.stats()["filter_form"] == 2 and np.array_equal(r.download(), bounded)
+    r.close()
+    _, st = gpu_render(Scene.load(scene_file("s1"), 96, 54, 2))                  # two large triangles
     assert st["filter_form"] == 1 and st["flagged_rays"] == 0
     _, st = gpu_render(Scene.load(scene_file("campanile_teddy"), 192, 108, 2))
     assert st["filter_form"] == 2 and st["flagged_rays"] == 0

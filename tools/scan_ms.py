@@ -11,6 +11,8 @@ scene = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "scenes", "teap
 w, h, d = (int(x) for x in sys.argv[2:5]) if len(sys.argv) > 4 else (3840, 2160, 5)
 n = 5
 r = Renderer(Scene.load(scene, w, h, d))
+if os.environ.get("FORM"):                       # FORM=1|2: the static or the per-test margins of the filter, whatever the upload chose
+    r.set_option(abi.RT_OPT_FILTER_FORM, int(os.environ["FORM"]))
 for _ in range(2):
     r.render_tiles(0, 16, world)
 torch.cuda.synchronize()
