@@ -94,7 +94,7 @@ typedef enum rt_option {
                                 (raytracer.cpp:319-321: a ray that starts exactly in a triangle's plane and grazes it
                                 "hits" at its own origin wherever the triangle is), which no box hierarchy can find, is
                                 covered by a scan of its own behind the traversals where the frame needs it
-                                (RT_OPT_BVH_PLANE_GUARD).  Blocks (build, and one calibration frame).
+                                (RT_OPT_IN_PLANE_ORIGIN).  Blocks (build, and the calibration frame of that option if it is still due).
                                 The traversal walks four-wide nodes (each binary node with its internal children
                                 replaced by theirs); 2: walk the binary tree itself (same frames, ~15 % slower) */
     RT_OPT_FILTER_FORM = 5,  /* form of the FP32 candidate filter: 0 = chosen from the scene's own numbers
@@ -126,20 +126,26 @@ typedef enum rt_option {
                                  triangle range; 0 (default): the scans convert.  Same bits either way: frames,
                                  pair lists and counters are identical.  Measured on the 4K teapot frame: the
                                  scans 1-3 % faster, the frame 1.5-2.5 % slower (the extra stores) -- hence off */
-    RT_OPT_BVH_PLANE_GUARD = 12, /* In LBVH mode a traversal can be followed by a scan that asks the in-plane-origin
-                                 question alone (camera rays: the triangles in whose plane the eye may lie; shadow
-                                 rays: the triangles a ray towards the light can graze; reflection rays: clusters of
-                                 triangles whose planes can hold a ray's origin and a grazing direction) and hands
-                                 what it finds to the reference-precision test, so that LBVH frames equal brute-force
-                                 frames without exception.  It costs about as much as the traversal itself (4K teapot
-                                 frame: 4.2 -> 8.1 ms) and far more on large meshes, and almost no scene needs it.
-                                 2 (default): decided once per context, when RT_OPT_USE_BVH is first switched on --
-                                 camera, frame size and depth belong to the scene, so every render call traces the same
-                                 rays: one whole frame is traced with the scan on (blocking; its counts stay out of the
-                                 statistics), and the scan is kept for the render calls iff some pair of that frame
-                                 took the branch.  1: always on.  0: traversal only -- the LBVH then differs from the
-                                 reference exactly where a ray takes that branch on a triangle whose box it does not
-                                 reach */
+    RT_OPT_IN_PLANE_ORIGIN = 12, /* Triangle::intersection (raytracer.cpp:319-321) lets a ray that starts exactly in a
+                                 triangle's plane and grazes it "hit" that triangle at the ray's own origin, wherever in
+                                 the plane the triangle lies.  Asking that question of every ray is what the bounded
+                                 scans keep their naming machinery for (camera rays: the triangles in whose plane the
+                                 eye may lie; shadow rays: the triangles a ray towards the light can graze; reflection
+                                 rays: clusters of triangles whose planes can hold a ray's origin and a grazing
+                                 direction), and in LBVH mode a scan of that kind behind every traversal (no box
+                                 hierarchy finds such a hit); it costs a fifth of the benchmark frame by brute force and
+                                 doubles its LBVH frame, and almost no scene has a ray that takes the branch.
+                                 2 (default): decided once per context -- camera, frame size and depth belong to the
+                                 scene, so every render call traces the same rays: the first render call (or
+                                 RT_OPT_USE_BVH) first traces one whole frame with the question asked everywhere
+                                 (blocking; into the context's own frame buffer, its counts stay out of the
+                                 statistics), and the question is asked from then on iff some pair of that frame took
+                                 the branch.  Frames equal the reference's either way.  Until that frame has been
+                                 traced the question is asked (rt_render_tile_noalloc and rt_primary_hits never
+                                 start it).  1: always asked.  0: never -- frames then differ from the reference
+                                 exactly where a ray takes that branch (in LBVH mode: on a triangle whose box it
+                                 does not reach) */
+    RT_OPT_BVH_PLANE_GUARD = 12, /* (earlier name of RT_OPT_IN_PLANE_ORIGIN) */
     RT_OPT_FRAMES_IN_FLIGHT = 11 /* 1 (default): a render call's work runs on the caller's stream (and the internal
                                  stream of RT_OPT_OVERLAP, joined back before the call's last kernel).  2..8: that
                                  many render calls may be in flight at once: call i runs on internal streams of its
@@ -202,7 +208,8 @@ typedef struct rt_stats {
     double camera_ms;        /* RT_OPT_PROFILE: the part of closest_ms spent in launches of camera rays with
                                 RT_OPT_BOUNDING_TESTS on (the others scan rays that have nothing in common) */
     uint32_t camera_launches;
-    uint32_t bvh_plane_guard; /* 1: LBVH mode with the in-plane-origin scan behind the traversals (RT_OPT_BVH_PLANE_GUARD) */
+    uint32_t bvh_plane_guard; /* 1: the in-plane-origin question is asked (RT_OPT_IN_PLANE_ORIGIN; in LBVH mode: the scan
+                                 behind the traversals runs) */
     rt_scan_work scan_work[RT_SCAN_KINDS];   /* RT_OPT_WORK_COUNTERS */
     double scan_ms[RT_SCAN_KINDS];           /* RT_OPT_PROFILE: summed duration of the scan launches by kind (a shadow
                                                 launch holds both kinds of light: booked under the kind of light 0) */

@@ -15,7 +15,8 @@ RT_OPT_BOUNDING_TESTS = 8
 RT_OPT_WORK_COUNTERS = 9
 RT_OPT_SCAN_COPIES = 10
 RT_OPT_FRAMES_IN_FLIGHT = 11
-RT_OPT_BVH_PLANE_GUARD = 12
+RT_OPT_IN_PLANE_ORIGIN = 12
+RT_OPT_BVH_PLANE_GUARD = 12          # (earlier name)
 SCAN_KINDS = ["plain_nearest", "camera", "shadow_point", "shadow_directional", "reflection", "plain_shadow"]
 
 

@@ -56,6 +56,7 @@ int resolve_scratch(int device) {
 #include "rt_context.h"
 #include "rt_workspace.h"
 #include "rt_lanes.h"
+static int calibrate_plane(rt_ctx* c);          // (render_rows starts the calibration frame of RT_OPT_IN_PLANE_ORIGIN when it is due)
 #include "rt_pass.h"
 
 static int upload_scene(rt_ctx** out, const rt_scene_desc* d);
@@ -84,9 +85,6 @@ int rt_upload_scene(rt_ctx** out, const rt_scene_desc* d) {
 
 extern "C" {
 
-// RT_OPT_BVH_PLANE_GUARD = 2: one whole frame through the LBVH with the in-plane-origin scan behind every traversal,
-// into the context's own frame buffer, its counts kept out of the statistics.  The scan stays on iff some pair of that
-// frame took the in-plane-origin branch of Triangle::intersection (raytracer.cpp:319-321).
 // Installs the form of the filter the options now ask for, if it is not the one installed (and rebuilds the LBVH over
 // the new slot order when the context uses one).
 static int reinstall_form(rt_ctx* c) {
@@ -99,36 +97,44 @@ static int reinstall_form(rt_ctx* c) {
     return 0;
 }
 
-static int calibrate_bvh_guard(rt_ctx* c) {
-    if (c->bvh_guard_mode != 2) { c->bvh_guard = c->bvh_guard_mode; return 0; }
-    if (c->bvh_guard_calibrated) { c->bvh_guard = c->bvh_guard_found ? 1 : 0; return 0; }
+// RT_OPT_IN_PLANE_ORIGIN = 2: traces one whole frame, in the mode the context is in, with the in-plane-origin question
+// asked everywhere, and keeps the question iff some pair of that frame took the branch (rt_ctx::plane_mode).  The
+// frame goes to the context's own frame buffer, its counts stay out of the statistics.
+static int calibrate_plane(rt_ctx* c) {
+    if (c->plane_mode != 2 || c->plane_calibrated || c->calibrating) return 0;
     const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = sync_all(c);
+    if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
     DevCounters before;
     HIP_TRY(hipMemcpy(&before, c->counters.p, sizeof before, hipMemcpyDeviceToHost));
-    std::vector<unsigned long long> tally(2 * (size_t)c->aux_grid * 4);
-    HIP_TRY(hipMemcpy(tally.data(), c->bvh_tally.p, tally.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> tally;
+    if (c->bvh_tally.p) {
+        tally.resize(2 * (size_t)c->aux_grid * 4);
+        HIP_TRY(hipMemcpy(tally.data(), c->bvh_tally.p, tally.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    }
     uint32_t* const frame = c->frame;
-    const int in_flight = c->in_flight, profile = c->profile, work = c->work_counters, use = c->use_bvh, exact = c->force_exact;
+    const int in_flight = c->in_flight, profile = c->profile, work = c->work_counters, exact = c->force_exact;
     c->frame = c->own_frame.p; c->in_flight = 1; c->profile = 0; c->work_counters = 0; c->force_exact = 0;
-    c->use_bvh = 1; c->bvh_guard = 1;
-    int rc = render_rows(c, 0, c->hs.height, c->hs.height, 1, nullptr);
+    c->calibrating = true;
+    rc = render_rows(c, 0, c->hs.height, c->hs.height, 1, nullptr);
     hipError_t e = hipDeviceSynchronize();
-    c->frame = frame; c->in_flight = in_flight; c->profile = profile; c->work_counters = work; c->use_bvh = use; c->force_exact = exact;
+    c->calibrating = false;
+    c->frame = frame; c->in_flight = in_flight; c->profile = profile; c->work_counters = work; c->force_exact = exact;
     if (rc) return rc;
-    if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("LBVH calibration frame: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("calibration frame: ") + hipGetErrorString(e));
     DevCounters after;
     HIP_TRY(hipMemcpy(&after, c->counters.p, sizeof after, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(c->counters.p, &before, sizeof before, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->bvh_tally.p, tally.data(), tally.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    if (!tally.empty()) HIP_TRY(hipMemcpy(c->bvh_tally.p, tally.data(), tally.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(c->own_frame.p, 0, (size_t)c->hs.width * c->hs.height * 4));
-    c->bvh_guard_found = after.in_plane_origin_hits - before.in_plane_origin_hits;
-    c->bvh_guard_calibrated = true;
-    c->bvh_guard = c->bvh_guard_found ? 1 : 0;
-    c->bvh_guard_calibration_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    c->plane_found = after.in_plane_origin_hits - before.in_plane_origin_hits;
+    c->plane_calibrated = true;
+    c->plane_calibration_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (std::getenv("RT_GUARD_REPORT"))
-        fprintf(stderr, "LBVH in-plane-origin scan: calibration frame found %llu such pairs in %.3f s: scan %s\n",
-                c->bvh_guard_found, c->bvh_guard_calibration_s, c->bvh_guard ? "on" : "off");
+        fprintf(stderr, "in-plane-origin question: the calibration frame found %llu pairs that take the branch, in %.3f s: %s\n",
+                c->plane_found, c->plane_calibration_s, c->plane_found ? "asked" : "not asked");
     return 0;
 }
 
@@ -168,11 +174,9 @@ int rt_set_option(rt_ctx* c, int option, int64_t value) {
             if (value > 1) return probe_lane_streams(c);
             return 0;
         }
-        case RT_OPT_BVH_PLANE_GUARD:
-            if (value < 0 || value > 2) return fail(RT_ERR_ARG, "rt_set_option: the LBVH's in-plane-origin scan is 0 (off), 1 (on) or 2 (decided by a calibration frame)");
-            c->bvh_guard_mode = (int)value;
-            c->bvh_guard = value == 2 ? 1 : (int)value;
-            if (c->use_bvh) return calibrate_bvh_guard(c);
+        case RT_OPT_IN_PLANE_ORIGIN:
+            if (value < 0 || value > 2) return fail(RT_ERR_ARG, "rt_set_option: the in-plane-origin question is 0 (never asked), 1 (always) or 2 (decided by a calibration frame)");
+            c->plane_mode = (int)value;
             return 0;
         case RT_OPT_BOUNDING_TESTS:
             c->pretest = value ? 1 : 0; c->pretest_any = value == 1 ? 1 : 0;
@@ -182,10 +186,10 @@ int rt_set_option(rt_ctx* c, int option, int64_t value) {
                 HIP_TRY(hipSetDevice(c->device));
                 int rc = build_bvh(c);
                 if (rc) return rc;
-                rc = calibrate_bvh_guard(c);
-                if (rc) return rc;
             }
             c->use_bvh = value == 2 ? 2 : (value ? 1 : 0);      // 1: four-wide nodes, 2: the binary tree they are made from
+            // (the calibration frame of RT_OPT_IN_PLANE_ORIGIN, if still due, here rather than inside the first render call)
+            if (value) return calibrate_plane(c);
             return 0;
         default: return fail(RT_ERR_ARG, "rt_set_option: unknown option");
     }
@@ -463,7 +467,7 @@ int rt_get_stats(rt_ctx* c, rt_stats* out) {
     out->closest_ms = c->ms[0] + c->ms[1] + c->ms[4]; out->anyhit_ms = c->ms[2] + c->ms[3] + c->ms[5];
     out->closest_launches = c->launches[0] + c->launches[1] + c->launches[4];
     out->anyhit_launches = c->launches[2] + c->launches[3] + c->launches[5];
-    out->camera_ms = c->ms[1]; out->camera_launches = c->launches[1]; out->bvh_plane_guard = (c->use_bvh && c->bvh_guard) ? 1u : 0u;
+    out->camera_ms = c->ms[1]; out->camera_launches = c->launches[1]; out->bvh_plane_guard = plane_asked(c) ? 1u : 0u;
     out->exact_ms = c->ms[RT_WORK_KINDS]; out->exact_launches = c->launches[RT_WORK_KINDS];
     static_assert(RT_WORK_KINDS == RT_SCAN_KINDS && sizeof(rt_scan_work) == RT_WORK_FIELDS * sizeof(uint64_t), "scan work layout");
     HIP_TRY(hipMemcpy(out->scan_work, c->work.p, sizeof out->scan_work, hipMemcpyDeviceToHost));

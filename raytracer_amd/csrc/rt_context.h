@@ -154,15 +154,18 @@ struct rt_ctx {
     DevBuf<float> cl_camera, cl_lights, cl_sphere, cl_normal;
     DevBuf<int32_t> graze_slots, graze_start;   // per light: the triangles a shadow ray can graze (see TraceArgs)
     int n_clusters = 0;
-    // RT_OPT_BVH_PLANE_GUARD: behind every LBVH traversal, the scan that asks the in-plane-origin question alone.
-    // Mode 2 (default) decides once per context, when the LBVH is first switched on: the frame's rays are the same
-    // in every render call (camera, size and depth belong to the scene), so one whole frame traced with the scan on
-    // tells whether any pair of it takes that branch at all; only then is the scan kept.
-    int bvh_guard_mode = 2;
-    int bvh_guard = 1;                    // the scan runs (mode 1, or mode 2 after a calibration frame that found such pairs)
-    bool bvh_guard_calibrated = false;
-    unsigned long long bvh_guard_found = 0;   // in-plane-origin pairs of the calibration frame
-    double bvh_guard_calibration_s = 0;
+    // RT_OPT_IN_PLANE_ORIGIN: the in-plane-origin question (raytracer.cpp:319-321: a ray that starts exactly in a
+    // triangle's plane and grazes it "hits" at its own origin, wherever in the plane the triangle is).  Asking it costs
+    // the bounded scans their naming machinery (graze lists, cluster normals, every triangle in whose plane an origin
+    // lies visited) and the LBVH a scan behind every traversal, and almost no scene has a ray that takes the branch.
+    // Mode 2 (default) decides once per context: camera, frame size and depth belong to the scene, so every render call
+    // traces the same rays; one whole frame traced with the question asked everywhere tells whether any pair of it
+    // takes the branch at all, and only then is the question kept.  Until that frame has been traced it is asked.
+    int plane_mode = 2;                   // RT_OPT_IN_PLANE_ORIGIN: 0 never asked, 1 always, 2 decided by a calibration frame
+    bool plane_calibrated = false;
+    unsigned long long plane_found = 0;   // pairs of the calibration frame that took the branch
+    double plane_calibration_s = 0;
+    bool calibrating = false;             // the calibration frame is being rendered (it must not start another)
     int n_eye_plane = 0;                  // regular triangles in whose plane the eye may lie (FP32 bound): the camera rays' candidates
     size_t n_graze = 0;                   // entries of all lights' graze lists: the shadow rays' candidates
     int n_regular_real = 0;               // regular triangles without the copies that fill up the axis ranges

@@ -102,7 +102,7 @@ __device__ __forceinline__ void brute_scan(const DevScene* __restrict__ sc, cons
     const unsigned int n_tasks = n_ray_blocks * (unsigned int)split;
     const float eps = (MODE == 0) ? sc->eps : sc->shadow_eps;
     const int n_groups = (MODE == 0) ? sc->n_groups : 1;
-    unsigned int n_exact = 0;
+    unsigned int n_exact = 0, n_q7 = 0;       // (n_q7: pairs that took the in-plane-origin branch, raytracer.cpp:319-321)
 
     for (unsigned int task = wave_id; task < n_tasks; task += n_waves) {
         const int part = __builtin_amdgcn_readfirstlane((int)(task / n_ray_blocks));
@@ -152,7 +152,9 @@ __device__ __forceinline__ void brute_scan(const DevScene* __restrict__ sc, cons
             to_object_space(X, ident, &pos, &vec);
             if (part == 0 && valid) {
                 for (int i = ibeg; i < iend; i++) {
-                    const float t = tri_intersect_exact(exact[i], pos, vec, eps);
+                    bool q7 = false;
+                    const float t = tri_intersect_exact(exact[i], pos, vec, eps, &q7);
+                    if (q7) n_q7++;
                     publish_result<MODE>(A, ray, n_hits, t, exact[i].obj, pos, vec, X, ident, source);
                     n_exact++;
                 }
@@ -174,7 +176,9 @@ __device__ __forceinline__ void brute_scan(const DevScene* __restrict__ sc, cons
                     const int bsource = __shfl(source, src);
                     for (int j = pbeg + lane; j < pend; j += RT_WAVE) {
                         if (exact[j].hole) continue;
-                        const float t = tri_intersect_exact(exact[j], bpos, bvec, eps);
+                        bool q7 = false;
+                        const float t = tri_intersect_exact(exact[j], bpos, bvec, eps, &q7);
+                        if (q7) n_q7++;
                         publish_result<MODE>(A, bray, n_hits, t, exact[j].obj, bpos, bvec, X, ident, bsource);
                         n_exact++;
                     }
@@ -182,8 +186,9 @@ __device__ __forceinline__ void brute_scan(const DevScene* __restrict__ sc, cons
             }
         }
     }
-    for (int off = 32; off > 0; off >>= 1) n_exact += __shfl_xor(n_exact, off);
+    for (int off = 32; off > 0; off >>= 1) { n_exact += __shfl_xor(n_exact, off); n_q7 += __shfl_xor(n_q7, off); }
     if (lane == 0 && n_exact) atomicAdd(&A.counters->exact_tests, (unsigned long long)n_exact);
+    if (lane == 0 && n_q7) atomicAdd(&A.counters->in_plane_origin_hits, (unsigned long long)n_q7);
 }
 
 // The last kernel of a trace launch: brute_scan, and the housekeeping that spares every launch a fill in front of it.

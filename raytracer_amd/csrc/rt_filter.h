@@ -546,7 +546,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
             // ... then the triangles, one per lane, RT_GROUPS_AHEAD groups per round: of the clusters that
             // passed, and (reflection rays) of those a member of which could be named, for that question alone
             unsigned long long todo = cl_reach;
-            if (PRE == 4) todo |= __ballot(lane < n_grp && cluster_named((cbeg >> 6) + lane));
+            if (PRE == 4 && A.plane_guard) todo |= __ballot(lane < n_grp && cluster_named((cbeg >> 6) + lane));
             while (todo != 0ull) {
                 int gi[RT_GROUPS_AHEAD];
                 float4 rec[RT_GROUPS_AHEAD], pl[RT_GROUPS_AHEAD];
@@ -558,7 +558,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                     rec[u] = make_float4(0.f, 0.f, 0.f, 0.f); pl[u] = rec[u];
                     if (gi[u] >= 0 && j < cend) {
                         if (PRE != 4 || ((cl_reach >> gi[u]) & 1ull)) rec[u] = *(const float4*)(guard.bounds + 4 * (size_t)j);
-                        if (PRE == 4) pl[u] = *(const float4*)(guard.planes + 4 * (size_t)j);
+                        if (PRE == 4 && A.plane_guard) pl[u] = *(const float4*)(guard.planes + 4 * (size_t)j);
                     }
                 }
 #pragma unroll
@@ -588,7 +588,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                     }
                 }
             }
-            if (PRE == 2 || PRE == 3) {
+            if ((PRE == 2 || PRE == 3) && A.plane_guard) {
                 // The plane guard: the light's graze-list entries inside this chunk, one per lane.  An entry is
                 // named when the light is close enough to its plane for THIS task's rays (the list was cut for
                 // the whole scene's) and the plane passes through the box around the task's origins.
@@ -1063,7 +1063,9 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
             const double* X = sc->xforms + 48 * (size_t)__builtin_amdgcn_readfirstlane(G.xf);
             if (fax[0] >= fax[3]) continue;
             const GroupFilter& GQ = G.q[MODE];
-            const FilterQuery fp = {uniform_f(GQ.r_lo), uniform_f(GQ.a_zero), uniform_f(GQ.b_hi)};
+            // (the in-plane-origin question not asked, TraceArgs::plane_guard: no plane distance is "at most a_zero", and
+            // every place that names a triangle for that question compares against it)
+            const FilterQuery fp = {uniform_f(GQ.r_lo), A.plane_guard ? uniform_f(GQ.a_zero) : -INFINITY, uniform_f(GQ.b_hi)};
             // (shadow rays: every group carries the same two bounds, those of world-space rays)
             const float ob = uniform_f(GQ.origin_bound), vb = uniform_f(GQ.dir_len2_bound);
             // FP32 copies of the lane's rays in this group's object space

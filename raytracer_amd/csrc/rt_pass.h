@@ -25,6 +25,13 @@ struct Timed {
 // `events`: false for the entry point that allocates nothing (event timing creates events).
 // Blocks for a kernel that streams `items` queue entries (four per thread), between one block per compute unit and
 // the full grid.
+// Is the in-plane-origin question asked now (rt_ctx::plane_mode)?  Until the calibration frame has been traced: yes.
+bool plane_asked(const rt_ctx* c) {
+    if (c->calibrating) return true;
+    if (c->plane_mode != 2) return c->plane_mode == 1;
+    return c->plane_calibrated ? c->plane_found > 0 : true;
+}
+
 int blocks_for(const rt_ctx* c, size_t items) {
     const size_t blocks = (items + 4 * RT_BLOCK - 1) / (4 * RT_BLOCK);
     return (int)std::min<size_t>((size_t)c->aux_grid, std::max<size_t>((size_t)c->n_cu, blocks));
@@ -41,6 +48,7 @@ int launch_trace(rt_ctx* c, const Workspace& W, TraceArgs A, hipStream_t st, siz
     const int pair_grid = blocks_for(c, 4 * est_rays + est_rays);               // the listed pairs: a few per ray, four per thread
     A.camera_rays = (MODE == 0 && camera_rays) ? 1 : 0;
     A.beside_others = c->cur ? 1 : 0;
+    A.plane_guard = plane_asked(c) ? 1 : 0;
     A.shared_origin_a = (MODE == 0 && camera_rays && c->shared_consts) ? c->eye_a.p : nullptr;
     A.shared_dir_rinv = (MODE == 1 && c->shared_consts && c->dir_rinv.n > 0) ? c->dir_rinv.p : nullptr;
     A.light_dir_row = c->light_dir_row.p;
@@ -107,7 +115,7 @@ int launch_trace(rt_ctx* c, const Workspace& W, TraceArgs A, hipStream_t st, siz
             // machinery for that question -- camera rays: the triangles the host found the eye's plane distance too
             // small for; shadow rays: the lights' graze lists; reflection rays: clusters whose normal cone and sphere
             // admit such a plane -- lists the candidates, k_exact_pairs (below) decides them.
-            guard_scan = c->bvh_guard && ((MODE == 0 && camera_rays) ? c->n_eye_plane > 0
+            guard_scan = plane_asked(c) && ((MODE == 0 && camera_rays) ? c->n_eye_plane > 0
                                           : MODE == 0 ? c->sphere_any.n > 0 : (c->n_graze > 0 && c->bound_lights.n > 0));
             if (guard_scan) {
                 TraceArgs GA = A;
@@ -378,6 +386,8 @@ int run_pass(rt_ctx* c, const Workspace& ws, PassDesc pd, int nrows, hipStream_t
 // Rows y_start + j*stride_rows + [0, tile_rows) for j = 0 .. n_tiles-1 (clipped to the frame).
 int render_rows(rt_ctx* c, int y_start, int tile_rows, int stride_rows, int n_tiles, hipStream_t st) {
     HIP_TRY(hipSetDevice(c->device));
+    // (the first render call of a context traces the calibration frame of RT_OPT_IN_PLANE_ORIGIN first)
+    if (int rc = calibrate_plane(c)) return rc;
     const int H = c->hs.height, W = c->hs.width;
     // valid rows form a prefix of the pass's row sequence: only the last tile can be clipped
     long long total_rows = 0;

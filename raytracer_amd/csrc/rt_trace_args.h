@@ -88,6 +88,9 @@ struct TraceArgs {
     // (a hit "at the ray's own origin" on a triangle whose box the ray never reaches).  Launched behind the LBVH
     // traversal; what it lists goes through k_exact_pairs like any other pair.
     int32_t in_plane_only;
+    // 0: the in-plane-origin question is not asked at all -- nothing is named for it, no pair is listed for it.  Right only
+    // when it is known that no ray of the frame takes that branch of Triangle::intersection (rt_ctx::plane_guard).
+    int32_t plane_guard;
 };
 
 // Executed work of the scans, counted per wave in registers and added to TraceArgs::work at the
