@@ -542,7 +542,7 @@ def main():
                 "in_plane_origin_scan": "on" if sb["bvh_plane_guard"] else "off (the calibration frame found no ray that needs it)",
                 "note": "frames byte-identical to brute force (tests/test_gpu_bvh.py); the in-plane-origin hit that no box hierarchy finds "
                         "(raytracer.cpp:319-321) is covered by a scan behind the traversals, kept only when a calibration frame of "
-                        "this scene and camera shows a ray that takes that branch (RT_OPT_BVH_PLANE_GUARD in include/rt_abi.h)"}
+                        "this scene and camera shows a ray that takes that branch (RT_OPT_IN_PLANE_ORIGIN in include/rt_abi.h)"}
 
     rays_local = st_timed["rays_primary"] + st_timed["rays_reflect"] + st_timed["rays_shadow"]
     if world > 1:
@@ -659,6 +659,12 @@ def main():
                                                 "same K frames with one call in flight",
                        "frames_in_flight_queues": lane_deal,
                        "triangles": n_tri, "spheres": n_sph, "lights": scene.desc.n_lights,
+                       "filter_form": {1: "static margins", 2: "per-test margins"}.get(st_timed["filter_form"], st_timed["filter_form"]),
+                       "in_plane_origin_question": ("asked" if st_timed["bvh_plane_guard"] else
+                                                    "not asked: the calibration frame of this scene and camera, traced with the question "
+                                                    "asked of every ray, found no pair that takes that branch of Triangle::intersection "
+                                                    "(raytracer.cpp:319-321; RT_OPT_IN_PLANE_ORIGIN in include/rt_abi.h); frames equal "
+                                                    "the reference's either way"),
                        "tile_rows": args.tile_rows, "parallelism": f"interleaved scanline tiles x{world}",
                        "rays_per_frame": {"primary": n_primary // args.steps, "reflect": n_reflect // args.steps,
                                           "shadow": n_shadow // args.steps,
@@ -675,6 +681,7 @@ def main():
                  "traffic": measured_traffic(0 if "<0," in dom else 1, 0) if world == 1 and launches else None,
                  "traffic_source": "replayed from the committed PMC summary under profiles/ (not measured in this run)",
                  "kernel_ms_avg": ms / max(1, launches), "launches": launches,
+                 "filter_form": {1: "static margins", 2: "per-test margins"}.get(st["filter_form"], st["filter_form"]),
                  "flop_per_test": flop_per_test, "tests_per_launch": tests / max(1, launches),
                  "both_filter_kernels_tflops": both / 1e12,
                  "filter_ms_per_step": both_ms / args.steps,

@@ -257,3 +257,49 @@ def test_in_plane_origin_branch_of_shadow_and_reflected_rays(oracle, tmp_path):
     _, _, g_occl, g_hit1, _ = r.bounce_probe(sc.desc.n_lights)
     r.close()
     assert (g_hit1[on] != hit1[on]).any() or (g_occl[on] != occl[on]).any()
+
+
+def test_in_plane_origin_question_is_decided_by_the_frame(tmp_path):
+    """RT_OPT_IN_PLANE_ORIGIN = 2 (default): the first render call first traces the whole frame with the question asked of
+    every ray, and keeps asking iff some pair took the branch.  A scene without such a pair is then traced without the
+    naming machinery -- same frame, same counts, fewer pairs for the re-test -- and a scene with one keeps it (the
+    tests above run in this mode).  Until a frame has been traced the question is asked; rt_primary_hits does not
+    start the calibration; the explicit settings win."""
+    from raytracer_amd.render import Renderer
+    sc = Scene.load(os.path.join(ROOT, "scenes", "teapot.scene"), 160, 90, 4)
+    always = Renderer(sc)
+    always.set_option(abi.RT_OPT_IN_PLANE_ORIGIN, 1)
+    always.render_frame()
+    want, st_always = always.download(), always.stats()
+    always.close()
+    assert st_always["bvh_plane_guard"] == 1 and st_always["in_plane_origin_hits"] == 0
+    for bvh in (0, 1):
+        r = Renderer(sc)
+        assert r.stats()["bvh_plane_guard"] == 1          # (not decided yet: asked)
+        r.primary_hits()
+        assert r.stats()["bvh_plane_guard"] == 1
+        if bvh:
+            r.set_option(abi.RT_OPT_USE_BVH, 1)             # (the calibration frame is traced here, through the LBVH)
+            assert r.stats()["bvh_plane_guard"] == 0
+        r.reset_stats()
+        r.render_frame()
+        got, st = r.download(), r.stats()
+        assert st["bvh_plane_guard"] == 0
+        assert np.array_equal(got, want)
+        for k in ("rays_primary", "rays_reflect", "rays_shadow", "hits", "closest_tests", "anyhit_tests"):
+            assert st[k] == st_always[k], k                 # (one frame's counts: the calibration frame's are not in them)
+        if not bvh:
+            assert st["exact_tests"] <= st_always["exact_tests"]
+        r.set_option(abi.RT_OPT_IN_PLANE_ORIGIN, 1)
+        r.render_frame()
+        assert r.stats()["bvh_plane_guard"] == 1 and np.array_equal(r.download(), want)
+        r.set_option(abi.RT_OPT_IN_PLANE_ORIGIN, 2)
+        assert r.stats()["bvh_plane_guard"] == 0          # (decided once per context)
+        r.close()
+    path = tmp_path / "in_plane.scene"
+    path.write_text(IN_PLANE_SCENE)
+    r = Renderer(Scene.load(str(path), 80, 80, 2))
+    r.render_frame()
+    st = r.stats()
+    assert st["bvh_plane_guard"] == 1 and st["in_plane_origin_hits"] >= 4 * 80
+    r.close()
