@@ -563,6 +563,16 @@ def main():
     del frames, pipe
     torch.cuda.empty_cache()
     leg_steps = max(1, min(3, args.steps))
+    # The headline once more with the in-plane-origin question asked of every ray whatever the calibration frame found
+    # (RT_OPT_IN_PLANE_ORIGIN = 1): what the question costs, and the figure for a scene that needs it.
+    always_asked = None
+    if not args.exact_only and not args.no_lbvh:
+        from raytracer_amd import abi as _abi
+        a = run_frames(job, args, scene, args.steps, in_flight, options=[(_abi.RT_OPT_IN_PLANE_ORIGIN, 1)])
+        always_asked = {"ms_per_step": a["ms_per_step"], "Mrays_per_s": a["Mrays_per_s"], "steps": a["steps"],
+                        "frames_in_flight": a["frames_in_flight"],
+                        "note": "same frames; the timed configuration asks the question only if the calibration frame of the "
+                                "scene and camera shows a pair that takes that branch (config.in_plane_origin_question)"}
     config4 = config4_leg(job, args, leg_steps, in_flight) if not args.no_config4 and not args.exact_only else None
     config5 = config5_leg(job, args, leg_steps, in_flight) if not args.no_config5 and not args.exact_only else None
 
@@ -739,6 +749,8 @@ def main():
             line["lbvh"] = lbvh
         if config4 is not None:
             line["config4"] = config4
+        if always_asked is not None:
+            line["in_plane_origin_question_always_asked"] = always_asked
         if config5 is not None:
             line["config5"] = config5
         line["config"]["exchange"] = ("one transfer per tile, straight into rank 0's frame rows" if args.exchange == "tiles"
