@@ -359,6 +359,7 @@ int rt_bounce_probe(rt_ctx* c, int y0, int rows, double* point, double* refl, ui
         ha.sc = dsc; ha.cur = q[0]; ha.next = q[1]; ha.keys = ws.keys[0]; ha.next_keys = ws.keys[1];
         ha.n_rays = ws.counts; ha.n_hits = ws.counts + 1; ha.lvl = lvl; ha.aux = aux;
         ha.hit_counts = ws.hit_counts;
+        ha.camera_rays = 1;
         ha.occluded = ws.occluded[0]; ha.occl_words = words;
         ha.shadow_scan = scan_shadow ? ws.shadow_scan[0] : nullptr; ha.shadow_stride = (uint32_t)ws.cap;
         ha.light_frame = c->light_frame.p;

@@ -19,6 +19,7 @@ struct HitArgs {
     LevelStore lvl;
     int32_t* parent_next;                // the level above's LevelStore::next (null: none kept, or the camera rays' level)
     int32_t chain;                       // 1: keep the chains (LevelStore::next) for k_fold_all
+    int32_t camera_rays;                 // 1: `cur` holds the pass's camera rays (origin = the eye, not stored)
     HitAux aux;
     uint32_t* occluded;
     int32_t occl_words;
@@ -119,7 +120,8 @@ k_hit(HitArgs A) {
         const int xf = sc->obj_transform[obj];
         const double* X = sc->xforms + 48 * (size_t)xf;
         const int ident = sc->xf_identity[xf];
-        d3 wpos = mk3(A.cur.ox[i], A.cur.oy[i], A.cur.oz[i]);
+        // (camera rays all start at the eye; their queue holds no origins)
+        d3 wpos = A.camera_rays ? ld3(sc->cam_eye) : mk3(A.cur.ox[i], A.cur.oy[i], A.cur.oz[i]);
         d3 wvec = mk3(A.cur.dx[i], A.cur.dy[i], A.cur.dz[i]);
         d3 rpos = wpos, rvec = wvec;
         if (!ident) { rpos = xf_point(X + 16, wpos); rvec = xf_dir(X + 16, wvec); }

@@ -321,6 +321,7 @@ int run_pass(rt_ctx* c, const Workspace& ws, PassDesc pd, int nrows, hipStream_t
         ha.n_rays = ws.counts + k; ha.n_hits = ws.counts + k + 1; ha.lvl = lvl; ha.aux = aux;
         ha.hit_counts = ws.hit_counts;
         ha.chain = chain ? 1 : 0;
+        ha.camera_rays = k == 0 ? 1 : 0;
         ha.parent_next = (chain && k > 0) ? level_of(ws, k - 1).next : nullptr;
         ha.occluded = occl; ha.occl_words = ws.occl_words;
         ha.shadow_scan = scan_shadow ? ws.shadow_scan[cur] : nullptr; ha.shadow_stride = (uint32_t)ws.cap;

@@ -154,7 +154,7 @@ k_primary(const DevScene* __restrict__ sc, PassDesc pd, int n_pix, RayQueue q,
         d3 c = add3(scl3(bottom, (double)(1 - v)), scl3(top, (double)v));
         d3 eye = ld3(sc->cam_eye);
         d3 dir = sub3(c, eye);
-        q.ox[p] = eye.x; q.oy[p] = eye.y; q.oz[p] = eye.z;
+        // (no origin is stored: every reader of a camera ray takes the eye, TraceArgs::camera_rays / HitArgs::camera_rays)
         q.dx[p] = dir.x; q.dy[p] = dir.y; q.dz[p] = dir.z;
         if (q.scan) {
             float ux, uy, uz;

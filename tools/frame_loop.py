@@ -8,7 +8,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 scene = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "scenes", "teapot.scene")
 w, h, d = (int(x) for x in sys.argv[3:6]) if len(sys.argv) > 5 else (3840, 2160, 5)
 r = Renderer(Scene.load(scene, w, h, d))
-r.set_option(abi.RT_OPT_OVERLAP, 0)
+r.set_option(abi.RT_OPT_OVERLAP, int(os.environ.get("OVERLAP", "0")))     # (OVERLAP=1: the library's two streams)
 for _ in range(n):
     r.render_frame()
 r.download()
