@@ -331,7 +331,8 @@ __device__ __forceinline__ bool filter_keep1(const float* __restrict__ f, int ax
     float m = __builtin_fminf(__builtin_fminf(s, t), u);
     if (robust) m = __builtin_fmaf(f[13 + mode], fabsf(rinv), m);
     const bool reject = (m < 0.0f) | (r < Q.r_lo);
-    const bool in_plane = robust ? ((fabsf(a) <= Q.a_zero) & (fabsf(b) <= Q.b_hi)) : (fabsf(a) <= Q.a_zero);
+    // (the in-plane-origin branch is the reference's only for a grazing ray, raytracer.cpp:319: both forms ask for one)
+    const bool in_plane = (fabsf(a) <= Q.a_zero) & (fabsf(b) <= Q.b_hi);
     // |r - reference's r| <= (Ea + |r| Eb) / |b| + rounding of the division and the product
     *r_lo_out = r - ((Q.e_a + fabsf(r) * Q.e_b) * fabsf(rinv) * 1.25f + fabsf(r) * 1e-6f);
     return (!reject) | in_plane;
