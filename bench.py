@@ -241,13 +241,23 @@ def run_frames(job, args, scene, steps, in_flight, options=()):
 def config4_leg(job, args, steps, in_flight):
     """campanile + teddy (23,243 triangles, 48 of them zero-area: the reference shadows every point, the frame is
     ambient light only), 7680 x 4320, depth 6, split over this job's ranks by interleaved tiles: brute force and
-    through the LBVH."""
+    through the LBVH.  A zero-area triangle is in the way of every shadow ray (raytracer.cpp:313, 553) and the library
+    knows so from the upload: its shadow launches mark the rays and test nothing.  The third leg takes that knowledge
+    away (RAYTRACER_AMD_TEST_VOID_NORMALS=1: every shadow ray scanned against every triangle, as in a scene without
+    such a triangle)."""
     from raytracer_amd import Scene, abi
     cw, ch = (int(v) for v in args.config_size.split("x"))
     sc = Scene.load(os.path.join(ROOT, "scenes", "campanile_teddy.scene"), cw, ch, 6)
-    return {"scene": "campanile_teddy.scene", "n_gpus": job.world,
-            "brute_force": run_frames(job, args, sc, steps, in_flight),
-            "lbvh": run_frames(job, args, sc, steps, in_flight, options=[(abi.RT_OPT_USE_BVH, 1)])}
+    out = {"scene": "campanile_teddy.scene", "n_gpus": job.world,
+           "shadow_rays": "answered at upload: a zero-area triangle shadows every ray, none is tested",
+           "brute_force": run_frames(job, args, sc, steps, in_flight),
+           "lbvh": run_frames(job, args, sc, steps, in_flight, options=[(abi.RT_OPT_USE_BVH, 1)])}
+    os.environ["RAYTRACER_AMD_TEST_VOID_NORMALS"] = "1"
+    try:
+        out["brute_force_shadow_rays_scanned"] = run_frames(job, args, sc, steps, in_flight)
+    finally:
+        del os.environ["RAYTRACER_AMD_TEST_VOID_NORMALS"]
+    return out
 
 
 def cpu_baseline(args, gpu_rays_fn):

@@ -107,6 +107,7 @@ struct rt_ctx {
     // by side on every CU instead of one filling the chip and the next taking over as it drains (four in flight:
     // 4.85 -> 4.70 ms per frame; a quarter of the blocks: 5.4 ms).
     int beside_grid_div = 2;
+    int n_void_normal = 0;                       // triangles whose unit normal is not a number: one of them shadows every ray (see brute_scan)
     bool fold_by_level = false;                  // RAYTRACER_AMD_FOLD_BY_LEVEL=1: the level-by-level fold whatever the depth (A/B, tests)
     // RT_OPT_FRAMES_IN_FLIGHT: render call i runs in lanes[i % in_flight] (none of this is used at 1)
     int in_flight = 1;

@@ -29,7 +29,9 @@ struct __attribute__((aligned(16))) TriExact {
     int32_t grp;       // index of the transform group; RT_GRP_IDENTITY set: the group's transform is the identity
                        // (whoever only needs to know that is spared the load of the group's record)
     float box_pad;     // how far outside the triangle the reference's own rounding can accept a point
-    int32_t hole;      // 1: no triangle here (a slot between the end of an axis range and the next multiple of 64)
+    int32_t hole;      // 1: no triangle here (a slot between the end of an axis range and the next multiple of 64);
+                       // 2 (irregular triangles only): the unit normal is not a number -- the reference's answer for this
+                       // triangle is then the same for every ray (see brute_scan), and no ray is tested against it
 };
 
 struct __attribute__((aligned(16))) SphereRec {
@@ -105,7 +107,7 @@ struct DevScene {
     int32_t n_prims_nominal;     // primitives of the scene (the copies that fill up the axis ranges not counted)
     float eps, shadow_eps;
     int32_t robust_filter;       // 1: filter records carry per-test margins (see filter_z2)
-    int32_t pad1;
+    int32_t n_void_normal;       // irregular triangles whose unit normal is not a number (TriExact::hole == 2, see brute_scan)
     double cam_eye[3], cam_ll[3], cam_lr[3], cam_ul[3], cam_ur[3];
     double ambient[3];
 };

@@ -90,8 +90,17 @@ __device__ __forceinline__ void brute_scan(const DevScene* __restrict__ sc, cons
     const unsigned int n_ray_blocks = (n_rays + RT_WAVE - 1) / RT_WAVE;
     if (n_ray_blocks == 0) return;
     const int NR = sc->n_regular, NI = sc->n_irregular, NS = sc->n_spheres;
+    // A triangle whose unit normal is not a number (zero area: 0 / 0 in raytracer.cpp:313) gives Triangle::intersection
+    // the same run for every ray: a, b and r are not numbers, every comparison of raytracer.cpp:319-355 is false, and
+    // it returns r.  As a nearest hit that never counts (its distance is not below MAXFLOAT, raytracer.cpp:525); for a
+    // shadow ray it always does (NaN != MAXFLOAT, raytracer.cpp:553; the source of a shadow ray is a nearest hit, so
+    // never such a triangle).  One such triangle in the scene therefore shadows every ray, and none is tested.
+    const bool all_shadowed = MODE == 1 && sc->n_void_normal > 0;
+    // objects that every ray takes to the reference's arithmetic (a shadow ray already in shadow takes none)
+    const int n_each_ray = (all_shadowed && !A.scan_all) ? 0 : NS + NI - sc->n_void_normal;
     // nothing but flagged rays could need this kernel, and no ray is flagged: done (one scalar load)
-    if (NS + NI == 0 && !A.scan_all && __builtin_amdgcn_readfirstlane(*(const volatile unsigned int*)A.any_flagged) == 0u) return;
+    if (n_each_ray == 0 && !all_shadowed && !A.scan_all &&
+        __builtin_amdgcn_readfirstlane(*(const volatile unsigned int*)A.any_flagged) == 0u) return;
     int max_split = (NR + 255) / 256;
     if (max_split < 1) max_split = 1;
     int split = 1;
@@ -115,11 +124,15 @@ __device__ __forceinline__ void brute_scan(const DevScene* __restrict__ sc, cons
             const unsigned long long m = __ballot(scan);
             if (lane == 0) atomicAdd(&A.counters->flagged_rays, (unsigned long long)__popcll(m));
         }
-        if (!any_scan && (part != 0 || NS + NI == 0)) continue;
+        if (all_shadowed && part == 0 && valid) {
+            unsigned int hit, light;
+            shadow_ray_index(ray, n_hits, &hit, &light);
+            atomicOr(&A.occluded[(size_t)hit * A.occl_words + (light >> 5)], 1u << (light & 31));
+        }
+        if (!any_scan && (part != 0 || n_each_ray == 0)) continue;
         d3 wpos = mk3(0, 0, 0), wvec = mk3(0, 0, 1);
         int source = -1;
         if (valid) load_world_ray<MODE>(A, sc, ray, n_hits, &wpos, &wvec, &source);
-
         if (part == 0 && valid) {
             // an FP32 pre-test decides most (ray, sphere) pairs; the rest take the reference's arithmetic
             const float fpx = (float)wpos.x, fpy = (float)wpos.y, fpz = (float)wpos.z;
@@ -152,6 +165,7 @@ __device__ __forceinline__ void brute_scan(const DevScene* __restrict__ sc, cons
             to_object_space(X, ident, &pos, &vec);
             if (part == 0 && valid) {
                 for (int i = ibeg; i < iend; i++) {
+                    if (exact[i].hole == 2) continue;             // (normal not a number: answered for all rays at once, above)
                     bool q7 = false;
                     const float t = tri_intersect_exact(exact[i], pos, vec, eps, &q7);
                     if (q7) n_q7++;

@@ -91,7 +91,10 @@ int launch_trace(rt_ctx* c, const Workspace& W, TraceArgs A, hipStream_t st, siz
     if (!W.flags_clean[MODE] || clear_always) HIP_TRY(hipMemsetAsync(W.ray_flags[MODE], 0, W.ray_flags_n[MODE], st));
     W.flags_clean[MODE] = false;
     bool guard_scan = false;              // LBVH mode: the in-plane-origin scan ran and listed pairs
-    if (!c->force_exact && c->hs.n_regular > 0) {
+    // A triangle whose unit normal is not a number is in the way of every shadow ray (see brute_scan, which marks them):
+    // traceShadowRay (raytracer.cpp:551-558) returns at the first object in the way, and this launch looks for no other.
+    const bool answered = MODE == 1 && c->n_void_normal > 0 && !c->force_exact;
+    if (!c->force_exact && c->hs.n_regular > 0 && !answered) {
         int scan_kind = MODE == 0 ? 0 : 5;
         if (!c->use_bvh) {
             if (MODE == 0 && A.cone_camera) scan_kind = 1;
@@ -163,7 +166,7 @@ int launch_trace(rt_ctx* c, const Workspace& W, TraceArgs A, hipStream_t st, siz
         t.stop();
     }
     Timed t(c, st, RT_WORK_KINDS, events);
-    if (!c->force_exact && c->hs.n_regular > 0 && (!c->use_bvh || guard_scan)) {      // (the LBVH traversal itself lists no pairs)
+    if (!c->force_exact && c->hs.n_regular > 0 && !answered && (!c->use_bvh || guard_scan)) {      // (the LBVH traversal itself lists no pairs)
         hipLaunchKernelGGL(k_exact_pairs<MODE>, dim3(pair_grid), dim3(RT_BLOCK), 0, st, dsc,
                            (const TriExact*)c->tri_exact.p, A);
         HIP_TRY(hipGetLastError());

@@ -191,10 +191,17 @@ int install_filter(rt_ctx* c, int robust) {
             slot[t.ex.obj] = (int32_t)k;
         }
     });
+    int n_void_normal = 0;
+    // (RAYTRACER_AMD_TEST_VOID_NORMALS=1, a diagnostic switch: such triangles are tested against every ray like the others)
+    const char* const void_env = std::getenv("RAYTRACER_AMD_TEST_VOID_NORMALS");
+    const bool test_void = void_env && std::atoi(void_env) != 0;
     for (int k = 0; k < NI; k++) {
         const HostTri& t = tris[order_irr[k]];
         exact[(size_t)NR + k] = t.ex;
-        exact[(size_t)NR + k].hole = 0;
+        // (zero-area triangle: (edge2 ^ edge1).normalize() is 0 / 0, raytracer.cpp:313)
+        const bool void_normal = !test_void && (std::isnan(t.ex.n[0]) || std::isnan(t.ex.n[1]) || std::isnan(t.ex.n[2]));
+        exact[(size_t)NR + k].hole = void_normal ? 2 : 0;
+        if (void_normal) n_void_normal++;
         slot[t.ex.obj] = NR + k;
     }
     std::vector<Group> groups;
@@ -523,6 +530,8 @@ int install_filter(rt_ctx* c, int robust) {
     s.n_regular = NR; s.n_irregular = NI; s.n_groups = (int)groups.size();
     s.n_prims_nominal = c->n_regular_real + NI + s.n_spheres;
     s.robust_filter = robust ? 1 : 0;
+    s.n_void_normal = n_void_normal;
+    c->n_void_normal = n_void_normal;
     std::vector<DevScene> one(1, s);
     HIP_TRY(c->d_scene.upload(one));
     c->robust = robust ? 1 : 0;

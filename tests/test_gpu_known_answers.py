@@ -303,3 +303,67 @@ def test_in_plane_origin_question_is_decided_by_the_frame(tmp_path):
     st = r.stats()
     assert st["bvh_plane_guard"] == 1 and st["in_plane_origin_hits"] >= 4 * 80
     r.close()
+
+
+# A sphere over a floor of two triangles, two lights, and one triangle of no area (two corners coincide) far behind
+# the camera.
+VOID_NORMAL_SCENE = """cam 0 1 6  -2 -1 3  2 -1 3  -2 2 3  2 2 3
+lta 0.2 0.25 0.3
+ltp 3 5 4  1 1 1
+ltd 0.2 -1 -0.3  0.6 0.6 0.6
+mat 0.3 0.2 0.1  0.6 0.5 0.4  0.5 0.5 0.5  20  0.4 0.4 0.4
+sph 0 0.2 0 1
+mat 0.2 0.3 0.2  0.5 0.6 0.5  0.2 0.2 0.2  8  0.3 0.3 0.3
+tri -6 -0.8 -6  -6 -0.8 6  6 -0.8 6
+tri -6 -0.8 -6  6 -0.8 6  6 -0.8 -6
+obj teapot.obj
+mat 0.5 0.5 0.5  0.5 0.5 0.5  0.5 0.5 0.5  2  0 0 0
+tri 0 0 50  0 0 50  1 1 50
+"""
+
+
+def test_a_triangle_of_no_area_shadows_every_point(oracle, tmp_path, monkeypatch):
+    """The unit normal of a triangle without area is 0 / 0 (raytracer.cpp:313), Triangle::intersection then returns a
+    NaN for every ray, and NaN != MAXFLOAT makes the triangle an occluder of every shadow ray (raytracer.cpp:553) while
+    it is never a nearest hit (raytracer.cpp:525): the frame is the ambient term plus reflections of ambient terms.
+    The library answers that at upload -- no shadow ray is tested against anything -- and must give the frame of
+    the long way round (RAYTRACER_AMD_TEST_VOID_NORMALS=1: the triangle is tested against every ray) and the oracle's
+    shadow bits, in every configuration."""
+    import shutil
+    from raytracer_amd.render import Renderer
+    from tests.oracle_api import compare
+    shutil.copy(os.path.join(ROOT, "scenes", "teapot.obj"), tmp_path / "teapot.obj")
+    path = tmp_path / "void_normal.scene"
+    path.write_text(VOID_NORMAL_SCENE)
+    sc = Scene.load(str(path), 96, 72, 3)
+    want, _ = oracle.render(sc)
+    hit0, _, _, want_occl, _, _ = oracle_bounce(oracle, sc)
+    on = hit0 >= 0
+    frames, stats = {}, {}
+    for long_way in ("1", "0"):
+        monkeypatch.setenv("RAYTRACER_AMD_TEST_VOID_NORMALS", long_way)
+        for label, opts in CONFIGS:
+            r = Renderer(sc)
+            for key, value in opts.items():
+                r.set_option(getattr(abi, "RT_OPT_" + key), value)
+            r.render_frame()
+            frames[long_way, label], stats[long_way, label] = r.download(), r.stats()
+            occl = r.bounce_probe(sc.desc.n_lights)[2]
+            r.close()
+            assert np.array_equal(occl[on], want_occl[on]) and (want_occl[on] == 3).all() and on.any(), (long_way, label)
+            worst, ndiff, _ = compare(frames[long_way, label], want)
+            assert worst <= 1, (long_way, label, worst, ndiff)
+    for label, _ in CONFIGS:
+        assert np.array_equal(frames["1", label], frames["0", label]), label
+        a, b = stats["1", label], stats["0", label]
+        for k in ("rays_primary", "rays_reflect", "rays_shadow", "hits"):
+            assert a[k] == b[k] and a[k] > 0, (label, k)
+        if label != "exact":
+            assert b["exact_tests"] < a["exact_tests"], label
+    # every point in shadow: no light's diffuse or specular term anywhere, so a frame without lights is the same frame
+    dark = tmp_path / "dark.scene"
+    dark.write_text("\n".join(l for l in VOID_NORMAL_SCENE.splitlines() if not l.startswith(("ltp", "ltd"))) + "\n")
+    r = Renderer(Scene.load(str(dark), 96, 72, 3))
+    r.render_frame()
+    assert np.array_equal(r.download(), frames["0", "static"])
+    r.close()
