@@ -108,6 +108,7 @@ struct rt_ctx {
     // 4.85 -> 4.70 ms per frame; a quarter of the blocks: 5.4 ms).
     int beside_grid_div = 2;
     int n_void_normal = 0;                       // triangles whose unit normal is not a number: one of them shadows every ray (see brute_scan)
+    int sphere_cull_min = 4;                     // RAYTRACER_AMD_SPHERE_CULL=n: spheres from which k_brute drops them wave by wave (0: never; A/B, tests)
     bool fold_by_level = false;                  // RAYTRACER_AMD_FOLD_BY_LEVEL=1: the level-by-level fold whatever the depth (A/B, tests)
     // RT_OPT_FRAMES_IN_FLIGHT: render call i runs in lanes[i % in_flight] (none of this is used at 1)
     int in_flight = 1;

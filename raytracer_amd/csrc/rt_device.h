@@ -50,6 +50,7 @@ struct __attribute__((aligned(16))) SphereFilt {
     float tabs;        // |m[0][3]| + |m[1][3]| + |m[2][3]| + |c|_1 (magnitudes that enter the object-space offset p - c)
     int32_t identity;  // the transform is the identity (rays stay as they are)
     int32_t pad;
+    float wc[3], wr;   // a ball in world space around the transformed sphere (nearest-hit queries; see spheres_in_reach)
 };
 
 // Thresholds of the FP32 candidate filter for one kind of query against one transform
@@ -239,6 +240,67 @@ __device__ __forceinline__ bool sphere_may_hit(const SphereFilt& F, const bool t
     const float dd_lo = dd - e_dd;
     const bool behind = (eps > 0.0f) & ((top < 0.0f) | ((dd_lo > 0.0f) & (top < eps * (1.0f - 1e-3f) * dd_lo)));
     return !(no_root | behind);
+}
+
+// What the 64 rays of a wave have in common, for dropping spheres for all of them at once: every origin lies within
+// `radius` of `m`, every direction within the angle alpha of the unit vector `d` (cos_a, sin_a; alpha < 90 degrees), so
+// every ray stays inside the cone of that angle around `d` whose apex lies `back` = radius / sin_a behind `m` (the cone
+// that touches the ball of the origins), and in front of the plane through m - radius * d across `d`.
+struct RayCone {
+    float mx, my, mz, radius;
+    float dx, dy, dz, back;
+    float cos_a, sin_a;
+    float p1_max;          // largest |x| + |y| + |z| of an origin (what the rays lost when they became floats scales with it)
+    bool usable;           // false: the rays have no such cone (too far apart in direction, or not finite); nothing is dropped
+};
+
+// (all lanes of the wave call this; `valid`: the lane holds a ray; p: origin, v: direction as floats)
+__device__ __forceinline__ RayCone ray_cone_of_wave(bool valid, float px, float py, float pz, float vx, float vy, float vz, float p1) {
+    RayCone C;
+    const float len2 = __builtin_fmaf(vx, vx, __builtin_fmaf(vy, vy, vz * vz));
+    const bool fine = !valid || (p1 < INFINITY && len2 > 1e-30f && len2 < INFINITY);      // (false for NaNs)
+    const float inv = valid && fine ? 1.0f / sqrtf(len2) : 0.0f;
+    const float ux = vx * inv, uy = vy * inv, uz = vz * inv;
+    float lo[3] = {valid ? px : INFINITY, valid ? py : INFINITY, valid ? pz : INFINITY};
+    float hi[3] = {valid ? px : -INFINITY, valid ? py : -INFINITY, valid ? pz : -INFINITY};
+    float sx = valid ? ux : 0.f, sy = valid ? uy : 0.f, sz = valid ? uz : 0.f, pm = valid ? p1 : 0.f;
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], off)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off)); }
+        sx += __shfl_xor(sx, off); sy += __shfl_xor(sy, off); sz += __shfl_xor(sz, off);
+        pm = fmaxf(pm, __shfl_xor(pm, off));
+    }
+    C.mx = 0.5f * (lo[0] + hi[0]); C.my = 0.5f * (lo[1] + hi[1]); C.mz = 0.5f * (lo[2] + hi[2]);
+    const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+    C.radius = 0.5f * sqrtf(__builtin_fmaf(ex, ex, __builtin_fmaf(ey, ey, ez * ez))) * 1.00001f + 1e-6f * pm;
+    const float sl = sqrtf(__builtin_fmaf(sx, sx, __builtin_fmaf(sy, sy, sz * sz)));
+    const float si = sl > 0.f ? 1.0f / sl : 0.f;
+    C.dx = sx * si; C.dy = sy * si; C.dz = sz * si;
+    float low = valid ? __builtin_fmaf(ux, C.dx, __builtin_fmaf(uy, C.dy, uz * C.dz)) : 1.0f;
+    for (int off = 32; off > 0; off >>= 1) low = fminf(low, __shfl_xor(low, off));
+    C.cos_a = fminf(low, 1.0f) - 1e-5f;               // (the angle from above: a cosine too small)
+    C.sin_a = sqrtf(fmaxf(1.0f - C.cos_a * C.cos_a, 0.f));
+    C.back = C.radius / C.sin_a;                      // (sin_a >= 4e-3 by the line above)
+    C.p1_max = pm;
+    C.usable = !__any(!fine) && sl > 0.f && C.cos_a > 0.2f && C.radius < INFINITY;
+    return C;
+}
+
+// May a ray of the wave meet the ball of radius r around c?  False only when the ball (grown by what the floats of this
+// test and of the rays can be off) lies outside the cone, or behind the plane the rays start from (then both roots of
+// raytracer.cpp:399-401 are negative, below an eps that is not: `behind_counts`).  NaNs compare false: kept.
+__device__ __forceinline__ bool ball_in_reach(const RayCone& C, float cx, float cy, float cz, float r, bool behind_counts) {
+    const float wx0 = cx - C.mx, wy0 = cy - C.my, wz0 = cz - C.mz;
+    const float wx = __builtin_fmaf(C.dx, C.back, wx0), wy = __builtin_fmaf(C.dy, C.back, wy0), wz = __builtin_fmaf(C.dz, C.back, wz0);   // from the apex
+    const float along = __builtin_fmaf(wx, C.dx, __builtin_fmaf(wy, C.dy, wz * C.dz));
+    const float kx = wy * C.dz - wz * C.dy, ky = wz * C.dx - wx * C.dz, kz = wx * C.dy - wy * C.dx;
+    const float across = sqrtf(__builtin_fmaf(kx, kx, __builtin_fmaf(ky, ky, kz * kz)));
+    const float dist = sqrtf(__builtin_fmaf(wx, wx, __builtin_fmaf(wy, wy, wz * wz)));
+    const float slack = 1e-4f * (dist + C.radius + r) + 1e-5f * (C.p1_max + fabsf(cx) + fabsf(cy) + fabsf(cz));
+    const bool outside = __builtin_fmaf(across, C.cos_a, -along * C.sin_a) > r + slack;
+    const float ahead = __builtin_fmaf(wx0, C.dx, __builtin_fmaf(wy0, C.dy, wz0 * C.dz));
+    const bool behind = behind_counts && (ahead + r + slack < -C.radius);
+    return !(outside || behind);
 }
 
 // The nearest-hit metric of Scene::traceRay (raytracer.cpp:522-524): distance

@@ -133,22 +133,67 @@ __device__ __forceinline__ void brute_scan(const DevScene* __restrict__ sc, cons
         d3 wpos = mk3(0, 0, 0), wvec = mk3(0, 0, 1);
         int source = -1;
         if (valid) load_world_ray<MODE>(A, sc, ray, n_hits, &wpos, &wvec, &source);
-        if (part == 0 && valid) {
+        if (part == 0 && NS > 0) {
             // an FP32 pre-test decides most (ray, sphere) pairs; the rest take the reference's arithmetic
             const float fpx = (float)wpos.x, fpy = (float)wpos.y, fpz = (float)wpos.z;
             const float fvx = (float)wvec.x, fvy = (float)wvec.y, fvz = (float)wvec.z;
             const float p1 = fabsf(fpx) + fabsf(fpy) + fabsf(fpz), v1 = fabsf(fvx) + fabsf(fvy) + fabsf(fvz);
-            for (int s = 0; s < NS; s++) {
-                const SphereFilt& F = sc->sphere_filt[s];
-                if (!A.scan_all && !sphere_may_hit(F, MODE == 0 && !F.identity, fpx, fpy, fpz, fvx, fvy, fvz, p1, v1, eps)) continue;
-                const SphereRec& S = sc->spheres[s];
-                const double* X = sc->xforms + 48 * (size_t)S.xf;
-                d3 pos = wpos, vec = wvec;
-                const int ident = (MODE == 0) ? S.identity : 1;   // shadow rays are never transformed (raytracer.cpp:553)
-                to_object_space(X, ident, &pos, &vec);
-                const float t = sph_intersect_exact(S, pos, vec, eps);
-                publish_result<MODE>(A, ray, n_hits, t, S.obj, pos, vec, X, ident, source);
-                n_exact++;
+            // With more than a few spheres the wave first drops those none of its rays can meet: the rays of a wave are
+            // neighbours in the frame (or the shadow rays of neighbours towards one light) and share a narrow cone; sphere
+            // s is judged by lane s, 64 at a time.
+            const bool cull = A.sphere_cull_min > 0 && NS >= A.sphere_cull_min && !A.scan_all;
+            RayCone cone;
+            if (cull) cone = ray_cone_of_wave(valid, fpx, fpy, fpz, fvx, fvy, fvz, p1);
+            for (int base = 0; base < NS; base += RT_WAVE) {
+                unsigned long long todo = ~0ull;
+                if (cull && cone.usable) {
+                    bool keep = false;
+                    if (base + lane < NS) {
+                        const SphereFilt& F = sc->sphere_filt[base + lane];
+                        // (shadow rays meet the untransformed sphere, raytracer.cpp:553)
+                        keep = (MODE == 0) ? ball_in_reach(cone, F.wc[0], F.wc[1], F.wc[2], F.wr, eps >= 0.0f)
+                                           : ball_in_reach(cone, F.c[0], F.c[1], F.c[2], sqrtf(F.r2) * 1.000001f, eps >= 0.0f);
+                    }
+                    todo = __ballot(keep);
+                }
+                if (NS - base < RT_WAVE) todo &= (1ull << (NS - base)) - 1ull;
+#ifdef RT_CHECK_SPHERE_CULL
+                // Diagnostic build (brute-force mode, where the LBVH's two counters are idle): every dropped (ray, sphere)
+                // pair is counted in bvh_leaf_tests and takes the reference's arithmetic all the same; one that hits is
+                // counted in bvh_node_tests, which must stay at zero.
+                {
+                    unsigned long long dropped = ~todo;
+                    if (NS - base < RT_WAVE) dropped &= (1ull << (NS - base)) - 1ull;
+                    unsigned int n_dropped = 0, n_wrong = 0;
+                    while (dropped != 0ull) {
+                        const int s = base + (int)__builtin_ctzll(dropped);
+                        dropped &= dropped - 1ull;
+                        if (!valid) continue;
+                        const SphereRec& S = sc->spheres[s];
+                        d3 pos = wpos, vec = wvec;
+                        to_object_space(sc->xforms + 48 * (size_t)S.xf, (MODE == 0) ? S.identity : 1, &pos, &vec);
+                        n_dropped++;
+                        if (sph_intersect_exact(S, pos, vec, eps) != RT_MISS_T) n_wrong++;
+                    }
+                    if (n_dropped) atomicAdd(&A.counters->bvh_leaf_tests, (unsigned long long)n_dropped);
+                    if (n_wrong) atomicAdd(&A.counters->bvh_node_tests, (unsigned long long)n_wrong);
+                }
+#endif
+                while (todo != 0ull) {
+                    const int s = base + (int)__builtin_ctzll(todo);
+                    todo &= todo - 1ull;
+                    if (!valid) continue;
+                    const SphereFilt& F = sc->sphere_filt[s];
+                    if (!A.scan_all && !sphere_may_hit(F, MODE == 0 && !F.identity, fpx, fpy, fpz, fvx, fvy, fvz, p1, v1, eps)) continue;
+                    const SphereRec& S = sc->spheres[s];
+                    const double* X = sc->xforms + 48 * (size_t)S.xf;
+                    d3 pos = wpos, vec = wvec;
+                    const int ident = (MODE == 0) ? S.identity : 1;   // shadow rays are never transformed (raytracer.cpp:553)
+                    to_object_space(X, ident, &pos, &vec);
+                    const float t = sph_intersect_exact(S, pos, vec, eps);
+                    publish_result<MODE>(A, ray, n_hits, t, S.obj, pos, vec, X, ident, source);
+                    n_exact++;
+                }
             }
         }
         for (int g = 0; g < n_groups; g++) {

@@ -49,6 +49,7 @@ int launch_trace(rt_ctx* c, const Workspace& W, TraceArgs A, hipStream_t st, siz
     A.camera_rays = (MODE == 0 && camera_rays) ? 1 : 0;
     A.beside_others = c->cur ? 1 : 0;
     A.plane_guard = plane_asked(c) ? 1 : 0;
+    A.sphere_cull_min = c->sphere_cull_min;
     A.shared_origin_a = (MODE == 0 && camera_rays && c->shared_consts) ? c->eye_a.p : nullptr;
     A.shared_dir_rinv = (MODE == 1 && c->shared_consts && c->dir_rinv.n > 0) ? c->dir_rinv.p : nullptr;
     A.light_dir_row = c->light_dir_row.p;

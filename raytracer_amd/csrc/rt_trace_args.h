@@ -91,6 +91,8 @@ struct TraceArgs {
     // 0: the in-plane-origin question is not asked at all -- nothing is named for it, no pair is listed for it.  Right only
     // when it is known that no ray of the frame takes that branch of Triangle::intersection (rt_ctx::plane_guard).
     int32_t plane_guard;
+    // k_brute drops spheres for a whole wave at a time (see ray_cone_of_wave) in scenes with at least this many; 0: never.
+    int32_t sphere_cull_min;
 };
 
 // Executed work of the scans, counted per wave in registers and added to TraceArgs::work at the

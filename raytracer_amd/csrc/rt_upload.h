@@ -744,6 +744,29 @@ static int upload_scene(rt_ctx** out, const rt_scene_desc* d) {
             for (int q = 0; q < 3; q++) { f.c[q] = (float)g[q]; f.tabs += (float)(std::fabs(g[q]) * (1 + 1e-6)); }
             f.r2 = (float)s.r2;
             f.identity = s.identity;
+            // A ball around the sphere's image in world space: centre M c, radius r * |M| with the 3 x 3 part's spectral
+            // norm bounded by sqrt(|M|_1 |M|_inf).  The rays meet the sphere through the inverse the reference computed
+            // (raytracer.cpp:246-247), so M must be that matrix's inverse to well within the test's slack; if not (a
+            // transform close to singular), no ball: the sphere is never dropped for a whole wave.
+            {
+                const double* M = &xf[48 * (size_t)s.xf];
+                double col[3] = {0, 0, 0}, n1 = 0, ninf = 0, off = 0;
+                for (int r = 0; r < 3; r++) {
+                    double row = 0;
+                    for (int q = 0; q < 3; q++) { row += std::fabs(M[4 * r + q]); col[q] += std::fabs(M[4 * r + q]); }
+                    ninf = std::max(ninf, row);
+                    f.wc[r] = (float)(M[4 * r] * g[0] + M[4 * r + 1] * g[1] + M[4 * r + 2] * g[2] + M[4 * r + 3]);
+                    for (int q = 0; q < 4; q++) {
+                        double e = (r == q) ? -1.0 : 0.0;
+                        for (int k = 0; k < 4; k++) e += I[4 * r + k] * M[4 * k + q];
+                        off = std::max(off, std::fabs(e));
+                    }
+                }
+                for (int q = 0; q < 3; q++) n1 = std::max(n1, col[q]);
+                const double scale = s.identity ? 1.0 : std::sqrt(n1 * ninf) * (1 + 1e-6);
+                f.wr = (off < 1e-6) ? (float)(std::fabs((double)radius) * scale * (1 + 1e-6)) : INFINITY;      // (false for NaNs: no ball)
+                if (s.identity) { f.wc[0] = f.c[0]; f.wc[1] = f.c[1]; f.wc[2] = f.c[2]; }
+            }
             // (a transform or sphere whose floats are not finite: the pre-test keeps every pair, NaNs compare false)
             sph_filt.push_back(f);
         } else {
@@ -958,6 +981,7 @@ static int upload_scene(rt_ctx** out, const rt_scene_desc* d) {
     c->aux_grid = c->n_cu * 8;
     if (const char* env = std::getenv("RAYTRACER_AMD_GRID_HINTS")) c->grid_hints = std::atoi(env) ? 1 : 0;
     if (const char* env = std::getenv("RAYTRACER_AMD_FOLD_BY_LEVEL")) c->fold_by_level = std::atoi(env) != 0;
+    if (const char* env = std::getenv("RAYTRACER_AMD_SPHERE_CULL")) c->sphere_cull_min = std::max(0, std::atoi(env));
     if (const char* env = std::getenv("RAYTRACER_AMD_BESIDE_DIV")) c->beside_grid_div = std::max(1, std::min(16, std::atoi(env)));
     // this device's copy of the static workspace (for rt_render_tile_noalloc)
     if (int rc = resolve_scratch(c->device)) return bail(rc);
