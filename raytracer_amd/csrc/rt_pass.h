@@ -87,9 +87,7 @@ int launch_trace(rt_ctx* c, const Workspace& W, TraceArgs A, hipStream_t st, siz
     // Headers and flags are at zero when a launch starts: the launches keep them so among themselves; only a workspace
     // that is new, or whose last launch of this kind was not enqueued to its end, is cleared here.
     // (RAYTRACER_AMD_CLEAR_EVERY_LAUNCH=1, a diagnostic switch: the fill in front of every launch all the same)
-    const char* const clear_env = std::getenv("RAYTRACER_AMD_CLEAR_EVERY_LAUNCH");
-    const bool clear_always = clear_env && std::atoi(clear_env) != 0;
-    if (!W.flags_clean[MODE] || clear_always) HIP_TRY(hipMemsetAsync(W.ray_flags[MODE], 0, W.ray_flags_n[MODE], st));
+    if (!W.flags_clean[MODE] || c->clear_every_launch) HIP_TRY(hipMemsetAsync(W.ray_flags[MODE], 0, W.ray_flags_n[MODE], st));
     W.flags_clean[MODE] = false;
     bool guard_scan = false;              // LBVH mode: the in-plane-origin scan ran and listed pairs
     // A triangle whose unit normal is not a number is in the way of every shadow ray (see brute_scan, which marks them):
