@@ -129,10 +129,19 @@ __device__ __forceinline__ void brute_scan(const DevScene* __restrict__ sc, cons
             shadow_ray_index(ray, n_hits, &hit, &light);
             atomicOr(&A.occluded[(size_t)hit * A.occl_words + (light >> 5)], 1u << (light & 31));
         }
-        if (!any_scan && (part != 0 || n_each_ray == 0)) continue;
+        // A shadow ray that the launch's earlier kernels (or an earlier object of this loop) found something in the way of
+        // asks no further object: traceShadowRay returns at the first one (raytracer.cpp:553-555).  (A bit another wave
+        // sets meanwhile may be missed; the ray then asks an object too many.)
+        bool live = valid;
+        if (MODE == 1 && !A.scan_all && part == 0 && valid && n_each_ray > 0) {
+            unsigned int hit, light;
+            shadow_ray_index(ray, n_hits, &hit, &light);
+            live = ((A.occluded[(size_t)hit * A.occl_words + (light >> 5)] >> (light & 31)) & 1u) == 0u;
+        }
+        if (!any_scan && (part != 0 || n_each_ray == 0 || !__any(live))) continue;
         d3 wpos = mk3(0, 0, 0), wvec = mk3(0, 0, 1);
         int source = -1;
-        if (valid) load_world_ray<MODE>(A, sc, ray, n_hits, &wpos, &wvec, &source);
+        if (live || scan) load_world_ray<MODE>(A, sc, ray, n_hits, &wpos, &wvec, &source);
         if (part == 0 && NS > 0) {
             // an FP32 pre-test decides most (ray, sphere) pairs; the rest take the reference's arithmetic
             const float fpx = (float)wpos.x, fpy = (float)wpos.y, fpz = (float)wpos.z;
@@ -143,7 +152,7 @@ __device__ __forceinline__ void brute_scan(const DevScene* __restrict__ sc, cons
             // s is judged by lane s, 64 at a time.
             const bool cull = A.sphere_cull_min > 0 && NS >= A.sphere_cull_min && !A.scan_all;
             RayCone cone;
-            if (cull) cone = ray_cone_of_wave(valid, fpx, fpy, fpz, fvx, fvy, fvz, p1);
+            if (cull) cone = ray_cone_of_wave(live, fpx, fpy, fpz, fvx, fvy, fvz, p1);
             for (int base = 0; base < NS; base += RT_WAVE) {
                 unsigned long long todo = ~0ull;
                 if (cull && cone.usable) {
@@ -168,7 +177,7 @@ __device__ __forceinline__ void brute_scan(const DevScene* __restrict__ sc, cons
                     while (dropped != 0ull) {
                         const int s = base + (int)__builtin_ctzll(dropped);
                         dropped &= dropped - 1ull;
-                        if (!valid) continue;
+                        if (!live) continue;
                         const SphereRec& S = sc->spheres[s];
                         d3 pos = wpos, vec = wvec;
                         to_object_space(sc->xforms + 48 * (size_t)S.xf, (MODE == 0) ? S.identity : 1, &pos, &vec);
@@ -182,7 +191,8 @@ __device__ __forceinline__ void brute_scan(const DevScene* __restrict__ sc, cons
                 while (todo != 0ull) {
                     const int s = base + (int)__builtin_ctzll(todo);
                     todo &= todo - 1ull;
-                    if (!valid) continue;
+                    if (MODE == 1 && !__any(live)) break;
+                    if (!live) continue;
                     const SphereFilt& F = sc->sphere_filt[s];
                     if (!A.scan_all && !sphere_may_hit(F, MODE == 0 && !F.identity, fpx, fpy, fpz, fvx, fvy, fvz, p1, v1, eps)) continue;
                     const SphereRec& S = sc->spheres[s];
@@ -193,6 +203,7 @@ __device__ __forceinline__ void brute_scan(const DevScene* __restrict__ sc, cons
                     const float t = sph_intersect_exact(S, pos, vec, eps);
                     publish_result<MODE>(A, ray, n_hits, t, S.obj, pos, vec, X, ident, source);
                     n_exact++;
+                    if (MODE == 1 && !A.scan_all && t != RT_MISS_T && S.obj != source) live = false;
                 }
             }
         }
@@ -208,7 +219,7 @@ __device__ __forceinline__ void brute_scan(const DevScene* __restrict__ sc, cons
             }
             d3 pos = wpos, vec = wvec;
             to_object_space(X, ident, &pos, &vec);
-            if (part == 0 && valid) {
+            if (part == 0 && live) {
                 for (int i = ibeg; i < iend; i++) {
                     if (exact[i].hole == 2) continue;             // (normal not a number: answered for all rays at once, above)
                     bool q7 = false;
@@ -216,6 +227,7 @@ __device__ __forceinline__ void brute_scan(const DevScene* __restrict__ sc, cons
                     if (q7) n_q7++;
                     publish_result<MODE>(A, ray, n_hits, t, exact[i].obj, pos, vec, X, ident, source);
                     n_exact++;
+                    if (MODE == 1 && !A.scan_all && t != RT_MISS_T && exact[i].obj != source) break;
                 }
             }
             if (any_scan) {
