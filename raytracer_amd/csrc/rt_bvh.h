@@ -427,9 +427,14 @@ k_bvh_trace(const DevScene* __restrict__ sc, BvhArgs B, TraceArgs A) {
         const bool valid = ray < n_rays;
         d3 wpos = mk3(0, 0, 0), wvec = mk3(0, 0, 1);
         int source = -1;
-        if (valid) load_world_ray<MODE>(A, sc, ray, n_hits, &wpos, &wvec, &source);
         // per-ray state
         bool active = valid;                            // still has boxes to visit or triangles staged
+        if (MODE == 1 && A.spheres == 2 && valid) {     // (a sphere is in the way already: k_spheres_first)
+            unsigned int hit, light;
+            shadow_ray_index(ray, n_hits, &hit, &light);
+            active = ((A.occluded[(size_t)hit * A.occl_words + (light >> 5)] >> (light & 31)) & 1u) == 0u;
+        }
+        if (active) load_world_ray<MODE>(A, sc, ray, n_hits, &wpos, &wvec, &source);
         bool bail = false;                              // this ray takes the full reference-precision scan instead
         bool need_group = true;                         // the current group is finished (or none was entered yet)
         int g = -1, cur = 0, sp = 0, n_staged = 0;

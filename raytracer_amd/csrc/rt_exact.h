@@ -89,28 +89,31 @@ __device__ __forceinline__ void brute_scan(const DevScene* __restrict__ sc, cons
     const unsigned int n_rays = (MODE == 0) ? n_hits : n_hits * n_lights;
     const unsigned int n_ray_blocks = (n_rays + RT_WAVE - 1) / RT_WAVE;
     if (n_ray_blocks == 0) return;
-    const int NR = sc->n_regular, NI = sc->n_irregular, NS = sc->n_spheres;
+    // (TraceArgs::spheres: 1 = this launch asks the spheres alone, 2 = an earlier kernel of the launch has asked them)
+    const int what = A.spheres;
+    const int NR = sc->n_regular, NI = (what == 1) ? 0 : sc->n_irregular, NS = (what == 2) ? 0 : sc->n_spheres;
+    const int n_void = (what == 1) ? 0 : sc->n_void_normal;
     // A triangle whose unit normal is not a number (zero area: 0 / 0 in raytracer.cpp:313) gives Triangle::intersection
     // the same run for every ray: a, b and r are not numbers, every comparison of raytracer.cpp:319-355 is false, and
     // it returns r.  As a nearest hit that never counts (its distance is not below MAXFLOAT, raytracer.cpp:525); for a
     // shadow ray it always does (NaN != MAXFLOAT, raytracer.cpp:553; the source of a shadow ray is a nearest hit, so
     // never such a triangle).  One such triangle in the scene therefore shadows every ray, and none is tested.
-    const bool all_shadowed = MODE == 1 && sc->n_void_normal > 0;
+    const bool all_shadowed = MODE == 1 && n_void > 0;
     // objects that every ray takes to the reference's arithmetic (a shadow ray already in shadow takes none)
-    const int n_each_ray = (all_shadowed && !A.scan_all) ? 0 : NS + NI - sc->n_void_normal;
+    const int n_each_ray = (all_shadowed && !A.scan_all) ? 0 : NS + NI - n_void;
     // nothing but flagged rays could need this kernel, and no ray is flagged: done (one scalar load)
     if (n_each_ray == 0 && !all_shadowed && !A.scan_all &&
-        __builtin_amdgcn_readfirstlane(*(const volatile unsigned int*)A.any_flagged) == 0u) return;
+        (what == 1 || __builtin_amdgcn_readfirstlane(*(const volatile unsigned int*)A.any_flagged) == 0u)) return;
     int max_split = (NR + 255) / 256;
     if (max_split < 1) max_split = 1;
     int split = 1;
-    if (n_ray_blocks < 2u * n_waves) {
+    if (what != 1 && n_ray_blocks < 2u * n_waves) {
         split = (int)((2u * n_waves + n_ray_blocks - 1) / n_ray_blocks);
         if (split > max_split) split = max_split;
     }
     const unsigned int n_tasks = n_ray_blocks * (unsigned int)split;
     const float eps = (MODE == 0) ? sc->eps : sc->shadow_eps;
-    const int n_groups = (MODE == 0) ? sc->n_groups : 1;
+    const int n_groups = (what == 1) ? 0 : (MODE == 0) ? sc->n_groups : 1;
     unsigned int n_exact = 0, n_q7 = 0;       // (n_q7: pairs that took the in-plane-origin branch, raytracer.cpp:319-321)
 
     for (unsigned int task = wave_id; task < n_tasks; task += n_waves) {
@@ -118,7 +121,7 @@ __device__ __forceinline__ void brute_scan(const DevScene* __restrict__ sc, cons
         const unsigned int rb = task - (unsigned int)part * n_ray_blocks;
         const unsigned int ray = rb * RT_WAVE + lane;
         const bool valid = ray < n_rays;
-        const bool scan = valid && (A.scan_all || A.ray_flags[ray] != 0);
+        const bool scan = what != 1 && valid && (A.scan_all || A.ray_flags[ray] != 0);
         const bool any_scan = __any(scan);
         if (part == 0 && !A.scan_all && any_scan) {
             const unsigned long long m = __ballot(scan);
@@ -266,6 +269,14 @@ __device__ __forceinline__ void brute_scan(const DevScene* __restrict__ sc, cons
 // Launches of one kind follow each other on a stream and take three headers and two flag arrays in turn; this launch
 // clears the flags of the launch before it, if that one set any (all blocks, a slice each), and the header of the launch
 // after it (block 0) -- memory that no kernel of this launch or of a launch still running touches otherwise.
+// The spheres alone, ahead of the launch's other kernels (TraceArgs::spheres = 1): a shadow ray that a sphere is in the
+// way of then asks no triangle (traceShadowRay returns at the first object in the way, raytracer.cpp:553-555).
+template <int MODE>
+__global__ void __launch_bounds__(RT_BLOCK)
+k_spheres_first(const DevScene* __restrict__ sc, const TriExact* __restrict__ exact, TraceArgs A) {
+    brute_scan<MODE>(sc, exact, A);
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(RT_BLOCK)
 k_brute(const DevScene* __restrict__ sc, const TriExact* __restrict__ exact, TraceArgs A) {

@@ -102,6 +102,14 @@ int launch_trace(rt_ctx* c, const Workspace& W, TraceArgs A, hipStream_t st, siz
         }
         Timed t(c, st, scan_kind, events);
         if (c->use_bvh) {
+            // In a scene of spheres the shadow rays ask those first (cheap, wave by wave): the traversal then starts only
+            // the rays that no sphere is in the way of.
+            if (MODE == 1 && c->sphere_cull_min > 0 && c->hs.n_spheres >= c->sphere_cull_min) {
+                TraceArgs SA = A;
+                SA.spheres = 1;
+                hipLaunchKernelGGL(k_spheres_first<MODE>, dim3(ray_grid), dim3(RT_BLOCK), 0, st, dsc, (const TriExact*)c->tri_exact.p, SA);
+                A.spheres = 2;
+            }
             BvhArgs ba;
             ba.bvh = c->bvh_groups.p; ba.nodes = c->bvh_nodes.p; ba.wide = c->bvh_wide.p; ba.filt = (const float*)c->tri_filt.p;
             ba.exact = c->tri_exact.p; ba.groups = c->groups.p; ba.xforms = c->xforms.p;

@@ -93,6 +93,9 @@ struct TraceArgs {
     int32_t plane_guard;
     // k_brute drops spheres for a whole wave at a time (see ray_cone_of_wave) in scenes with at least this many; 0: never.
     int32_t sphere_cull_min;
+    // 0: k_brute asks the spheres with everything else; 1: this kernel asks them alone (k_spheres_first); 2: that kernel ran
+    // ahead of this launch's others, which skip the spheres and the shadow rays it found something in the way of.
+    int32_t spheres;
 };
 
 // Executed work of the scans, counted per wave in registers and added to TraceArgs::work at the

@@ -429,6 +429,7 @@ def test_spheres_dropped_wave_by_wave(name, w, h, depth, oracle, tmp_path, monke
         assert a[1] == b[1], bvh
         for x, y in zip(a[2], b[2]):
             assert np.array_equal(x.view(np.uint8), y.view(np.uint8)), bvh
-        assert b[3] <= a[3]
+        if bvh == 0:            # (through the LBVH the spheres are then asked ahead of the traversal, also by rays a triangle shadows)
+            assert b[3] <= a[3]
     worst, ndiff, frac1 = compare(got["1", 0][0], want)
     assert worst <= 4 and frac1 >= 0.999, (worst, ndiff, frac1)      # (per-channel difference <= 1 on 99.9 % of the pixels, <= 4 everywhere)
