@@ -1,6 +1,6 @@
 // TEST INFRASTRUCTURE -- the reference program with its render() statement swapped for the MI355X library.
 //
-// This is the binding a maintainer of the reference would add (INTEGRATION.md shows the same code): the
+// This is the binding a maintainer of the reference would add: the
 // reference's own parser (parseSceneFile, raytracer.cpp:705), the walk over the public members of its Scene
 // that fills an rt_scene_desc, rt_upload_scene / rt_render_tile / rt_download in place of `scene->render()`
 // (raytracer.cpp:857), and the reference's own PNG encoder (lodepng::encode, raytracer.cpp:231) on the vector
