@@ -109,6 +109,7 @@ struct rt_ctx {
     int beside_grid_div = 2;
     int n_void_normal = 0;                       // triangles whose unit normal is not a number: one of them shadows every ray (see brute_scan)
     int sphere_cull_min = 4;                     // RAYTRACER_AMD_SPHERE_CULL=n: spheres from which k_brute drops them wave by wave (0: never; A/B, tests)
+    bool lean_scans = true;                      // RAYTRACER_AMD_LEAN_SCANS=0 (read at upload): the full instances of the scans also when the in-plane-origin question is not asked (A/B, tests)
     bool clear_every_launch = false;             // RAYTRACER_AMD_CLEAR_EVERY_LAUNCH=1 (read at upload): a fill in front of every trace launch (A/B, tests)
     bool fold_by_level = false;                  // RAYTRACER_AMD_FOLD_BY_LEVEL=1: the level-by-level fold whatever the depth (A/B, tests)
     // RT_OPT_FRAMES_IN_FLIGHT: render call i runs in lanes[i % in_flight] (none of this is used at 1)

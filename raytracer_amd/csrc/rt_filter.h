@@ -301,7 +301,11 @@ struct PlaneGuard {
 // refinement steps of sqrtf -- every use sits next to a relative slack of 1e-5 or more.
 __device__ __forceinline__ float judge_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
-template <int MODE, int RPL, int AXIS, bool ROBUST, int SHARED, int PRE, bool WORK>
+// PLANE = false: an instance for launches that do not ask the in-plane-origin question (TraceArgs::plane_guard == 0)
+// without the machinery that names triangles for it next to the bounding tests -- the plane records beside the bounding
+// records of a batch, the plane distances of the ray pairs, the clusters and graze-list entries named for it: a third
+// of the scalar registers of the reflection instance, and its scratch.
+template <int MODE, int RPL, int AXIS, bool ROBUST, int SHARED, int PRE, bool WORK, bool PLANE>
 __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* shared, const cv4f* cone,
                                              const PlaneGuard& guard, const TraceArgs& A,
                                              const FilterLane<RPL>& L, const FilterQuery fp, int abeg, int aend,
@@ -546,7 +550,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
             // ... then the triangles, one per lane, RT_GROUPS_AHEAD groups per round: of the clusters that
             // passed, and (reflection rays) of those a member of which could be named, for that question alone
             unsigned long long todo = cl_reach;
-            if (PRE == 4 && A.plane_guard) todo |= __ballot(lane < n_grp && cluster_named((cbeg >> 6) + lane));
+            if (PRE == 4 && PLANE && A.plane_guard) todo |= __ballot(lane < n_grp && cluster_named((cbeg >> 6) + lane));
             while (todo != 0ull) {
                 int gi[RT_GROUPS_AHEAD];
                 float4 rec[RT_GROUPS_AHEAD], pl[RT_GROUPS_AHEAD];
@@ -558,7 +562,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                     rec[u] = make_float4(0.f, 0.f, 0.f, 0.f); pl[u] = rec[u];
                     if (gi[u] >= 0 && j < cend) {
                         if (PRE != 4 || ((cl_reach >> gi[u]) & 1ull)) rec[u] = *(const float4*)(guard.bounds + 4 * (size_t)j);
-                        if (PRE == 4 && A.plane_guard) pl[u] = *(const float4*)(guard.planes + 4 * (size_t)j);
+                        if (PRE == 4 && PLANE && A.plane_guard) pl[u] = *(const float4*)(guard.planes + 4 * (size_t)j);
                     }
                 }
 #pragma unroll
@@ -588,7 +592,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                     }
                 }
             }
-            if ((PRE == 2 || PRE == 3) && A.plane_guard) {
+            if ((PRE == 2 || PRE == 3) && PLANE && A.plane_guard) {
                 // The plane guard: the light's graze-list entries inside this chunk, one per lane.  An entry is
                 // named when the light is close enough to its plane for THIS task's rays (the list was cut for
                 // the whole scene's) and the plane passes through the box around the task's origins.
@@ -686,10 +690,10 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                 if (!out_of_reach) {
                 if (nxt_index != j0) {
                     cones_nxt = *(const cv16u*)((const cfloat*)cone + 4 * (size_t)j0);
-                    if (PRE == 4) planes_nxt = *(const cv16u*)((const cfloat*)guard.planes + 4 * (size_t)j0);
+                    if (PRE == 4 && PLANE) planes_nxt = *(const cv16u*)((const cfloat*)guard.planes + 4 * (size_t)j0);
                 }
                 cones_cur = cones_nxt;
-                if (PRE == 4) planes_cur = planes_nxt;
+                if (PRE == 4 && PLANE) planes_cur = planes_nxt;
                 // the next wanted batch of this group (the first one of another group fetches its own records)
                 {
                     const int off = j0 - guard_base + RT_BATCH;
@@ -703,7 +707,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                     }
                     if (jl >= 0) {
                         cones_nxt = *(const cv16u*)((const cfloat*)cone + 4 * (size_t)jl);
-                        if (PRE == 4) planes_nxt = *(const cv16u*)((const cfloat*)guard.planes + 4 * (size_t)jl);
+                        if (PRE == 4 && PLANE) planes_nxt = *(const cv16u*)((const cfloat*)guard.planes + 4 * (size_t)jl);
                     }
                     nxt_index = jl;
                 }
@@ -771,7 +775,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                             const v2f cx = {cx1, cx1}, n0 = {nx1, nx1}, dd = {planes_cur[4 * jb + 3], planes_cur[4 * jb + 3]};
                             t[jb] = __builtin_elementwise_fma(cx, L.vx[q], -L.hx[q]);
                             d[jb] = cx * L.px[q];
-                            a[jb] = __builtin_elementwise_fma(-n0, L.px[q], dd);
+                            if (PLANE) a[jb] = __builtin_elementwise_fma(-n0, L.px[q], dd);
                         }
 #pragma unroll
                         for (int jb = 0; jb < RT_BATCH; jb++) {
@@ -779,7 +783,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                             const v2f cy = {cy1, cy1}, n1 = {ny1, ny1};
                             t[jb] = __builtin_elementwise_fma(cy, L.vy[q], t[jb]);
                             d[jb] = __builtin_elementwise_fma(cy, L.py[q], d[jb]);
-                            a[jb] = __builtin_elementwise_fma(-n1, L.py[q], a[jb]);
+                            if (PLANE) a[jb] = __builtin_elementwise_fma(-n1, L.py[q], a[jb]);
                         }
 #pragma unroll
                         for (int jb = 0; jb < RT_BATCH; jb++) {
@@ -787,7 +791,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                             const v2f cz = {cz1, cz1}, n2 = {nz1, nz1};
                             t[jb] = __builtin_elementwise_fma(cz, L.vz[q], t[jb]);
                             d[jb] = __builtin_elementwise_fma(cz, L.pz[q], d[jb]);
-                            a[jb] = __builtin_elementwise_fma(-n2, L.pz[q], a[jb]);
+                            if (PLANE) a[jb] = __builtin_elementwise_fma(-n2, L.pz[q], a[jb]);
                         }
 #pragma unroll
                         for (int jb = 0; jb < RT_BATCH; jb++) {
@@ -795,11 +799,11 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                             t[jb] = t[jb] * t[jb];
                             d[jb] = __builtin_elementwise_fma(-t[jb], L.hz[q], d[jb]);
                             low[jb] = __builtin_fminf(__builtin_fminf(low[jb], d[jb].x), d[jb].y);
-                            a_low[jb] = __builtin_fminf(__builtin_fminf(a_low[jb], fabsf(a[jb].x)), fabsf(a[jb].y));
+                            if (PLANE) a_low[jb] = __builtin_fminf(__builtin_fminf(a_low[jb], fabsf(a[jb].x)), fabsf(a[jb].y));
                         }
                     }
 #pragma unroll
-                    for (int jb = 0; jb < RT_BATCH; jb++) wants[jb] = (!guard_only & (low[jb] <= cones_cur[4 * jb + 3])) | (a_low[jb] <= fp.a_zero);
+                    for (int jb = 0; jb < RT_BATCH; jb++) wants[jb] = PLANE ? ((!guard_only & (low[jb] <= cones_cur[4 * jb + 3])) | (a_low[jb] <= fp.a_zero)) : (low[jb] <= cones_cur[4 * jb + 3]);
                 }
                 bool any_wanted = named != 0;
 #pragma unroll
@@ -867,7 +871,7 @@ __device__ __forceinline__ float uniform_f(float x) {      // a value every lane
     return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
 }
 
-template <int MODE, int RPL, bool ROBUST, int CONE, bool WORK = false>
+template <int MODE, int RPL, bool ROBUST, int CONE, bool WORK = false, bool PLANE = true>
 // The bounded instances are compiled for four waves per SIMD (128 registers; a few values spill to scratch).  Timed
 // alone a scan gains 3-6 % from the fourth wave and the frame nothing while one frame is in flight (the second
 // stream already fills the idle slots); with three frames in flight, where the sum of the work counts, the frame
@@ -1394,7 +1398,7 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                 const int aend = min(fax[axis] + alen, abeg + per_part);
                 if (abeg >= aend) continue;
                 constexpr int KIND = (MODE == 0) ? 1 : 2;
-#define RT_RANGE(AX, SH, PR) filter_range<MODE, RPL, AX, ROBUST, SH, PR, WORK>(filt, shared, cone, guard, A, L, fp, abeg, aend, my_cand, ray0, ray_end, lane, wk)
+#define RT_RANGE(AX, SH, PR) filter_range<MODE, RPL, AX, ROBUST, SH, PR, WORK, PLANE>(filt, shared, cone, guard, A, L, fp, abeg, aend, my_cand, ray0, ray_end, lane, wk)
                 if (CONE == 1) {
                     if (axis == 0) RT_RANGE(0, 1, 1);
                     if (axis == 1) RT_RANGE(1, 1, 1);
@@ -1417,7 +1421,7 @@ k_filter(const DevScene* __restrict__ sc, const v16f* __restrict__ filt_global, 
                         D.hx[k] = L.vx[k]; D.hy[k] = L.vy[k]; D.hz[k] = L.vz[k];
                         D.vx[k] = {sx, sx}; D.vy[k] = {sy, sy}; D.vz[k] = {sz, sz};
                     }
-#define RT_RANGE_D(AX) filter_range<MODE, RPL, AX, ROBUST, 2, 3, WORK>(filt, shared, cone, guard, A, D, fp, abeg, aend, my_cand, ray0, ray_end, lane, wk)
+#define RT_RANGE_D(AX) filter_range<MODE, RPL, AX, ROBUST, 2, 3, WORK, PLANE>(filt, shared, cone, guard, A, D, fp, abeg, aend, my_cand, ray0, ray_end, lane, wk)
                     if (axis == 0) RT_RANGE_D(0);
                     if (axis == 1) RT_RANGE_D(1);
                     if (axis == 2) RT_RANGE_D(2);

@@ -37,6 +37,16 @@ int blocks_for(const rt_ctx* c, size_t items) {
     return (int)std::min<size_t>((size_t)c->aux_grid, std::max<size_t>((size_t)c->n_cu, blocks));
 }
 
+// The instances of the shadow and reflection scans without the in-plane-origin machinery (k_filter's PLANE = false), for
+// launches that do not ask that question.
+template <int M, int R, int CN>
+static void launch_lean_filter(bool robust, dim3 grid, dim3 block, hipStream_t st, const DevScene* dsc, const v16f* records, const TraceArgs& A) {
+    if constexpr (CN == 2 || CN == 4) {
+        if (robust) hipLaunchKernelGGL((k_filter<M, R, true, CN, false, false>), grid, block, 0, st, dsc, records, A);
+        else hipLaunchKernelGGL((k_filter<M, R, false, CN, false, false>), grid, block, 0, st, dsc, records, A);
+    }
+}
+
 // `est_rays`: how many rays the queue is expected to hold (a hint, see PassHint; max_rays when nothing is known).
 template <int MODE>
 int launch_trace(rt_ctx* c, const Workspace& W, TraceArgs A, hipStream_t st, size_t max_rays, bool camera_rays = false,
@@ -158,6 +168,8 @@ int launch_trace(rt_ctx* c, const Workspace& W, TraceArgs A, hipStream_t st, siz
                 if (work) {                                                                                         \
                     if (c->robust) hipLaunchKernelGGL((k_filter<M, R, true, CN, true>), grid, block, 0, st, dsc, records, A);  \
                     else hipLaunchKernelGGL((k_filter<M, R, false, CN, true>), grid, block, 0, st, dsc, records, A); \
+                } else if ((CN == 2 || CN == 4) && !A.plane_guard && c->lean_scans) {                               \
+                    launch_lean_filter<M, R, CN>(c->robust != 0, grid, block, st, dsc, records, A);                 \
                 } else {                                                                                            \
                     if (c->robust) hipLaunchKernelGGL((k_filter<M, R, true, CN, false>), grid, block, 0, st, dsc, records, A); \
                     else hipLaunchKernelGGL((k_filter<M, R, false, CN, false>), grid, block, 0, st, dsc, records, A); \

@@ -981,6 +981,7 @@ static int upload_scene(rt_ctx** out, const rt_scene_desc* d) {
     c->aux_grid = c->n_cu * 8;
     if (const char* env = std::getenv("RAYTRACER_AMD_GRID_HINTS")) c->grid_hints = std::atoi(env) ? 1 : 0;
     if (const char* env = std::getenv("RAYTRACER_AMD_FOLD_BY_LEVEL")) c->fold_by_level = std::atoi(env) != 0;
+    if (const char* env = std::getenv("RAYTRACER_AMD_LEAN_SCANS")) c->lean_scans = std::atoi(env) != 0;
     if (const char* env = std::getenv("RAYTRACER_AMD_CLEAR_EVERY_LAUNCH")) c->clear_every_launch = std::atoi(env) != 0;
     if (const char* env = std::getenv("RAYTRACER_AMD_SPHERE_CULL")) c->sphere_cull_min = std::max(0, std::atoi(env));
     if (const char* env = std::getenv("RAYTRACER_AMD_BESIDE_DIV")) c->beside_grid_div = std::max(1, std::min(16, std::atoi(env)));
