@@ -383,7 +383,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
     // RT_GROUPS_AHEAD groups per round with all their records requested together (one memory
     // latency per round, not per group); group g's masks wait in lane g of a register pair, and
     // one bit per group says whether any triangle of it is wanted at all.
-    constexpr int NM = (PRE == 4) ? RPL / 2 : 2;
+    constexpr int NM = (PRE == 4) ? RPL / 2 : (PLANE ? 2 : 1);        // (masks kept per group: PRE 4 one per pair of ray slots; else reach, and named)
     int kept_lo[NM], kept_hi[NM];
 #pragma unroll
     for (int k = 0; k < NM; k++) { kept_lo[k] = 0; kept_hi[k] = 0; }
@@ -410,7 +410,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
     // Can the task's cone of directions from the shared point (PRE 1, 2) reach the cone `rec` (unit axis, cosine)
     // around a sphere?  Cones meet when the angle between their axes is at most the sum of their half-angles;
     // and the sphere's axis may leave the fan's plane by at most the two angles together.
-    const bool guard_only = A.in_plane_only != 0;          // (a kernel argument: wave-uniform)
+    const bool guard_only = PLANE && A.in_plane_only != 0;          // (a kernel argument: wave-uniform)
     auto cone_reach = [&](const float4 rec) -> bool {
         // (in-plane-origin question only, camera rays: the host marked the records of triangles -- and of clusters with
         // such a member -- in whose plane the eye may lie with "every direction", cos = -2)
@@ -447,15 +447,17 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                     const int sb = 2 * q + c;
                     if (guard.qon[sb] < 0) continue;                     // (wave-uniform: the bundle holds no ray)
                     if (guard.qon[sb] == 0) { live = true; continue; }
-                    // in-plane origin: the plane passes through the ball of origins and holds a grazing direction of the cone
-                    const float off = fabsf(pl.x * QB[sb].m[0] + pl.y * QB[sb].m[1] + pl.z * QB[sb].m[2] - pl.w);
-                    const float g = fabsf(pl.x * QB[sb].a[0] + pl.y * QB[sb].a[1] + pl.z * QB[sb].a[2]);
-                    // the smallest |n . v| over the cone is g cos - sqrt(1 - g^2) sin (<= 0: some v lies in the plane);
-                    // "at most the grazing bound" without the root: lhs = g cos - bound <= sqrt(1 - g^2) sin
-                    const float lhs = g * QB[sb].a[3] - QB[sb].graze;
-                    const bool grazing = !(lhs > 0.0f) | !(lhs * lhs > (1.0f - g * g) * QB[sb].a[4] * QB[sb].a[4] * (1.0f + 1e-5f));
-                    const bool is_named = !(off > QB[sb].m[4] + 2.0f * guard.slack) & grazing;
-                    live |= is_named;
+                    if constexpr (PLANE) {
+                        // in-plane origin: the plane passes through the ball of origins and holds a grazing direction of the cone
+                        const float off = fabsf(pl.x * QB[sb].m[0] + pl.y * QB[sb].m[1] + pl.z * QB[sb].m[2] - pl.w);
+                        const float g = fabsf(pl.x * QB[sb].a[0] + pl.y * QB[sb].a[1] + pl.z * QB[sb].a[2]);
+                        // the smallest |n . v| over the cone is g cos - sqrt(1 - g^2) sin (<= 0: some v lies in the plane);
+                        // "at most the grazing bound" without the root: lhs = g cos - bound <= sqrt(1 - g^2) sin
+                        const float lhs = g * QB[sb].a[3] - QB[sb].graze;
+                        const bool grazing = !(lhs > 0.0f) | !(lhs * lhs > (1.0f - g * g) * QB[sb].a[4] * QB[sb].a[4] * (1.0f + 1e-5f));
+                        const bool is_named = !(off > QB[sb].m[4] + 2.0f * guard.slack) & grazing;
+                        live |= is_named;
+                    }
                     if (reach_possible) live |= bundle_reach(sb, rec.x, rec.y, rec.z, rho);
                 }
                 live &= j < cend;
@@ -464,7 +466,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
         } else {
             bool in_reach = j < cend;
             if ((guard.cull || (PRE == 1 && guard_only)) && j < cend) in_reach = (PRE == 3) ? disc_reach(rec) : cone_reach(rec);
-            out[1] = 0ull;                               // (the plane guard's answers are added afterwards, see below)
+            if constexpr (PLANE) out[1] = 0ull;          // (the plane guard's answers are added afterwards, see below)
             out[0] = __ballot(in_reach);
         }
     };
@@ -592,7 +594,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                     }
                 }
             }
-            if ((PRE == 2 || PRE == 3) && PLANE && A.plane_guard) {
+            if constexpr ((PRE == 2 || PRE == 3) && PLANE) if (A.plane_guard) {
                 // The plane guard: the light's graze-list entries inside this chunk, one per lane.  An entry is
                 // named when the light is close enough to its plane for THIS task's rays (the list was cut for
                 // the whole scene's) and the plane passes through the box around the task's origins.
@@ -677,7 +679,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                             for (int q = 0; q < RPL / 2; q++) { pair_mask[q] = got[q]; reach_mask |= got[q]; }
                         } else {
                             reach_mask = got[0];
-                            guard_mask = got[1];
+                            if constexpr (PLANE) guard_mask = got[1];
                         }
                         guard_base = j0;
                         // on to the group's first wanted batch (a live group has one)
@@ -711,7 +713,7 @@ __device__ __forceinline__ void filter_range(const cv16f* filt, const cfloat* sh
                     }
                     nxt_index = jl;
                 }
-                if (PRE == 2 || PRE == 3) named = (unsigned int)(guard_mask >> (j0 - guard_base)) & ((1u << RT_BATCH) - 1u);
+                if ((PRE == 2 || PRE == 3) && PLANE) named = (unsigned int)(guard_mask >> (j0 - guard_base)) & ((1u << RT_BATCH) - 1u);
                 if (WORK) {
                     wk.v[RT_WK_BATCHES]++;
                     if (PRE != 4) wk.v[RT_WK_RAY_BOUND_TESTS] += RT_WAVE * RPL * RT_BATCH;
