@@ -367,21 +367,26 @@ def config5_leg(job, args, steps, in_flight):
 
 def pmc_of_kernel(mode, bounding_test):
     """The committed PMC passes of this same command (profiles/*pmc_summary.csv, written by tools/pmc_passes.sh +
-    tools/pmc_summary.py), for the scan kernel k_filter<MODE, rays per lane, form, bounding test, counting = false>:
+    tools/pmc_summary.py), for the scan kernel k_filter<MODE, rays per lane, form, bounding test, counting = false[, in-plane-origin machinery]>:
     (file name, {counter: sum over the DISPATCHES launches of one pass}).  (None, {}) when there is no such file or kernel."""
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.csv")), key=os.path.getmtime)
     if not files:
         return None, {}
-    got = {}
+    found = {}
     for r in csv.DictReader(open(files[-1])):
         name = r["kernel"].replace(" ", "")
         if not (name.startswith("k_filter<") and name.endswith(">")):
             continue
         targs = name[len("k_filter<"):-1].split(",")
-        if len(targs) == 5 and targs[0] == str(mode) and targs[3] == str(bounding_test) and targs[4] == "false":
-            got[r["counter"]] = float(r["sum_over_dispatches"])
+        if len(targs) in (5, 6) and targs[0] == str(mode) and targs[3] == str(bounding_test) and targs[4] == "false":
+            found.setdefault(name, {})[r["counter"]] = float(r["sum_over_dispatches"])
+    if not found:
+        return os.path.basename(files[-1]), {}
+    # (a sixth argument tells the instance with the in-plane-origin machinery from the one without: the timed configuration
+    # runs the one with the most launches in that command)
+    got = max(found.values(), key=lambda g: g.get("DISPATCHES", 0.0))
     return os.path.basename(files[-1]), got
 
 
