@@ -578,3 +578,42 @@ def test_the_two_folds_agree(name, w, h, depth, monkeypatch):
         assert np.array_equal(a, b), int((a != b).any(axis=-1).sum())
     assert frames["1"][3] == frames["0"][3]
     assert np.array_equal(frames["0"][0], frames["0"][2])
+
+
+@pytest.mark.parametrize("name,w,h,depth", [
+    ("teapot.scene", 320, 180, 5), ("mixed_xf.scene", 200, 150, 6), ("campanile_teddy.scene", 160, 90, 4),
+    ("synthetic_small.scene", 160, 90, 4), ("normals.scene", 128, 96, 3), ("scene3.scene", 160, 120, 2),
+])
+def test_scan_instances_without_the_in_plane_origin_machinery(name, w, h, depth, monkeypatch):
+    """Launches that do not ask the in-plane-origin question run instances of the shadow and reflection scans from which
+    the machinery for it is compiled out (k_filter's PLANE = false).  What is compiled out only ever added candidates
+    under a comparison that is false for such a launch: the frame, the ray counts and the number of listed pairs that
+    reach the reference's arithmetic equal those of the full instances (RAYTRACER_AMD_LEAN_SCANS=0), one call at a time
+    and three in flight, in both filter forms."""
+    from raytracer_amd.render import Renderer
+    monkeypatch.setenv("RAYTRACER_AMD_TEST_VOID_NORMALS", "1")        # (campanile: shadow rays are scanned, not answered at upload)
+    sc = Scene.load(os.path.join(ROOT, "scenes", name), w, h, depth)
+    got = {}
+    for lean in ("0", "1"):
+        monkeypatch.setenv("RAYTRACER_AMD_LEAN_SCANS", lean)
+        for form in (1, 2):
+            r = Renderer(sc)
+            r.set_option(abi.RT_OPT_FILTER_FORM, form)
+            r.render_frame()                   # (the calibration frame runs here; the counts below are one frame's)
+            r.reset_stats()
+            r.render_frame()
+            st = r.stats()
+            one = r.download()
+            r.set_option(abi.RT_OPT_FRAMES_IN_FLIGHT, 3)
+            for _ in range(4):
+                r.render_frame()
+            several = r.download()
+            r.close()
+            got[lean, form] = (one, several, st["bvh_plane_guard"],
+                               tuple(st[k] for k in ("rays_primary", "rays_reflect", "rays_shadow", "hits", "exact_tests", "flagged_rays")))
+    for form in (1, 2):
+        a, b = got["0", form], got["1", form]
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(b[0], b[1]), form
+        assert a[2] == b[2] and a[3] == b[3], (form, a[2:], b[2:])
+    if name == "teapot.scene":
+        assert got["1", 2][2] == 0              # (no ray of this frame takes the branch: the lean instances are the ones that ran)
