@@ -371,7 +371,7 @@ def pmc_of_kernel(mode, bounding_test):
     (file name, {counter: sum over the DISPATCHES launches of one pass}).  (None, {}) when there is no such file or kernel."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.csv")), key=os.path.getmtime)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.csv")), key=os.path.basename)   # (named per round: the last one)
     if not files:
         return None, {}
     found = {}
